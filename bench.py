@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- fine Wilson stencil apply on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one pass of the hot path over one synthetic right-hand side:
+    apply_stencil_2D_M  (stencil/stencil_2d.h:2571-2576)  ==  lhs = (clover + hopping + shift) rhs
+on the L x L even-odd lattice, Wilson nc = 2 (2 spin components over a U(1) gauge field), fp64.
+Default workload: L = 4096 (the north-star target); the 2048^2 configuration is timed as well and
+reported under "also".  Inputs are resident in HBM before the timed region.
+
+Multi-GPU: independent right-hand sides, one per rank, every rank holding a replica of the stencil
+(SURVEY 8e).  The apply has no exchange step, so there is no data-path collective: weak scaling,
+`value` = (sites processed by all ranks) * 176 flop / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- ALGORITHMIC bytes per launch (384 B/site: five 2x2 matrices + rhs + lhs)
+                  / average launch duration measured live with HIP events on the launch stream,
+                  against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the reference-structured CPU oracle (kind "port", 1 thread) timed on this box's host
+                  cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FLOP_PER_SITE = 176          # 8 nc^2 * 5 + 8 nc, nc = 2
+BYTES_PER_SITE = 384         # 5 nc^2 c + 2 nc c, c = 16 B
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MASS = -0.07                 # beta = 6.0, m_crit ~ -0.0706
+
+
+def site_index_grid(Lx, Ly):
+    x = np.arange(Lx, dtype=np.int64)[:, None]
+    y = np.arange(Ly, dtype=np.int64)[None, :]
+    p = (x + y) & 1
+    return (y + p * Ly) * (Lx // 2) + x // 2
+
+
+def tiled_gauge(L, fixture_path):
+    """Periodic tiling of the committed 64^2 U(1) fixture to L x L, in the reference's (mu,eo,y,x) layout."""
+    ph = np.loadtxt(fixture_path).reshape(64, 64, 2)
+    reps = L // 64
+    idx = site_index_grid(L, L)
+    g = np.empty(2 * L * L, dtype=np.complex128)
+    for mu in range(2):
+        u = np.exp(1j * np.tile(ph[:, :, mu], (reps, reps)))
+        g[mu * L * L + idx.reshape(-1)] = u.reshape(-1)
+    return g
+
+
+def tile_vector(v64, L, nc):
+    """Periodic tiling of a 64^2 (eo,y,x,c) vector to L^2 (for the size-independent parity gate)."""
+    grid = v64.reshape(64 * 64, nc)[site_index_grid(64, 64)]            # [x,y,c]
+    reps = L // 64
+    big = np.tile(grid, (reps, reps, 1))
+    out = np.empty((L * L, nc), dtype=np.complex128)
+    out[site_index_grid(L, L)] = big
+    return out.reshape(-1)
+
+
+class Workload:
+    def __init__(self, qmg, L, fixture, seed):
+        self.qmg, self.L = qmg, L
+        vol = L * L
+        g = qmg.DeviceArray.from_host(tiled_gauge(L, fixture))
+        self.clover = qmg.DeviceArray(4 * vol)
+        self.hopping = qmg.DeviceArray(16 * vol)
+        qmg.wilson_fill(self.clover, self.hopping, g, L, L, 1.0)
+        qmg.sync()
+        g.free()
+        self.desc = qmg.make_desc(L, L, 2, self.clover, self.hopping, MASS)
+        self.rhs = qmg.DeviceArray(2 * vol)
+        self.lhs = qmg.DeviceArray(2 * vol)
+        qmg.gaussian(self.rhs, 2 * vol, seed)
+        qmg.sync()
+
+    def step(self):
+        self.qmg.stencil_apply(self.desc, self.lhs, self.rhs, self.qmg.P_ALL | self.qmg.P_ZERO)
+
+    def parity_gate(self, fixture):
+        """GPU at full size vs the CPU oracle through periodicity: a 64-periodic rhs on the 64-periodic gauge
+        field gives the 64-periodic image of the oracle's 64^2 result."""
+        import oracle_lib as ol
+        qmg, L = self.qmg, self.L
+        ph = np.loadtxt(fixture)
+        clover, hopping = ol.wilson_fill(ol.phases_to_gauge_u1(ph, 64, 64), 64, 64)
+        rng = np.random.default_rng(1337)
+        v = rng.standard_normal(64 * 64 * 2) + 1j * rng.standard_normal(64 * 64 * 2)
+        want = tile_vector(ol.stencil_apply(ol.make_desc(64, 64, 2, clover, hopping, MASS), v), L, 2)
+        keep = self.rhs.to_host()
+        self.rhs.upload(tile_vector(v, L, 2))
+        self.step()
+        got = self.lhs.to_host()
+        self.rhs.upload(keep)
+        err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        if not err < 1e-13:
+            raise SystemExit("parity gate failed at L=%d: rel L2 error %.3e" % (L, err))
+        return err
+
+    def free(self):
+        for a in (self.clover, self.hopping, self.rhs, self.lhs):
+            a.free()
+
+
+def timed(qmg, wl, steps, warmup, barrier):
+    for _ in range(warmup):
+        wl.step()
+    qmg.sync()
+    timer = qmg.Timer()
+    barrier()
+    qmg.sync()
+    t0 = time.perf_counter()
+    timer.start()
+    for _ in range(steps):
+        wl.step()
+    ev_ms = timer.stop_ms()          # HIP events on the launch stream: synchronises on the stop event
+    qmg.sync()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, ev_ms / steps
+
+
+def cpu_baseline(fixture, budget_s=12.0):
+    """Reference-structured CPU path (oracle, 1 thread) on a bounded sample of the same workload."""
+    import oracle_lib as ol
+    L = 1024
+    gauge = tiled_gauge(L, fixture)
+    clover, hopping = ol.wilson_fill(gauge, L, L)
+    d = ol.make_desc(L, L, 2, clover, hopping, MASS)
+    rng = np.random.default_rng(7)
+    rhs = rng.standard_normal(2 * L * L) + 1j * rng.standard_normal(2 * L * L)
+    t1 = ol.time_apply(d, rhs, ol.P_ALL | ol.P_ZERO, 1)
+    reps = max(2, min(200, int(budget_s / max(t1, 1e-3))))
+    t = ol.time_apply(d, rhs, ol.P_ALL | ol.P_ZERO, reps) / reps
+    return {"value": FLOP_PER_SITE * L * L / t / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "Wilson apply_M, %dx%d tiled l64t64b60, %d applies, reference pass structure (8 cshift + 9 cMATxpy + 2 caxpy), g++ -O2" % (L, L, reps),
+            "ms_per_apply": t * 1e3, "gb_per_s_algorithmic": BYTES_PER_SITE * L * L / t / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--L", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    qmg = importlib.import_module("quantum-mg_amd")
+    if not os.path.exists(qmg.SO_PATH):
+        qmg.build()
+    qmg.init(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
+    L = args.L
+    wl = Workload(qmg, L, fixture, seed=1337 + rank)
+    gate_err = wl.parity_gate(fixture)
+    wall, kern_ms = timed(qmg, wl, args.steps, args.warmup, barrier)
+
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    sites = L * L
+    value = world * sites * FLOP_PER_SITE * args.steps / wall / 1e9
+    achieved = BYTES_PER_SITE * sites / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "fine Wilson stencil apply throughput", "value": value, "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+        "config": {"workload": "Wilson apply_stencil_2D_M, %dx%d U(1) (l64t64b60 tiled), nc=2, fp64, 1 rhs per GPU" % (L, L),
+                   "lattice": [L, L], "nc": 2, "mass": MASS, "rhs_per_gpu": 1, "parallelism": "independent rhs per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_stencil_elem<2>", "algorithmic_bytes_per_launch": BYTES_PER_SITE * sites,
+                     "avg_launch_ms": kern_ms},
+        "hbm_gb_per_s_aggregate": world * BYTES_PER_SITE * sites * args.steps / wall / 1e9,
+        "parity_gate_rel_l2": gate_err,
+    }
+    wl.free()
+
+    if rank == 0 and world == 1 and not args.no_also and L != 2048:
+        wl2 = Workload(qmg, 2048, fixture, seed=1337)
+        e2 = wl2.parity_gate(fixture)
+        w2, k2 = timed(qmg, wl2, args.steps, args.warmup, barrier)
+        s2 = 2048 * 2048
+        out["also"] = {"workload": "Wilson apply, 2048x2048 (BASELINE configs[1])", "gflops": s2 * FLOP_PER_SITE * args.steps / w2 / 1e9,
+                       "ms_per_step": w2 / args.steps * 1e3, "achieved_gb_per_s": BYTES_PER_SITE * s2 / (k2 * 1e-3) / 1e9,
+                       "frac_of_hbm_peak": BYTES_PER_SITE * s2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "parity_gate_rel_l2": e2,
+                       "note": "working set 1.6 GB; the 128 MiB vectors partly live in the 256 MiB Infinity Cache"}
+        wl2.free()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(fixture)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

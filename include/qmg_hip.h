@@ -1,0 +1,189 @@
+/* qmg_hip.h -- C-ABI of libqmg_hip.so: the MI355X (gfx950) drop-in for quantum-mg's
+ * multigrid hot path (stencil apply, cshift, restrict/prolong, global reductions).
+ *
+ * The reference (weinbe2/quantum-mg) is a header-only C++ library with no FFI of its own;
+ * its hot path is entered through the `matrix_op_cplx` callback
+ *     void (*)(complex<double>* lhs, complex<double>* rhs, void* extra_data)
+ * (stencil/stencil_2d.h:15-19) and through public methods of Stencil2D / TransferMG that
+ * operate on the PUBLIC arrays `clover`, `hopping`, `null_vectors` (stencil_2d.h:148-210,
+ * transfer/transfer.h:79).  This ABI is therefore STATELESS: every entry point takes the
+ * raw arrays + lattice extents exactly as the reference method receives them, except that
+ * all array pointers are DEVICE (HBM) addresses.  The reference's pointer-swap trick for
+ * operator variants (perform_swap_dagger, stencil_2d.h:1142-1178) maps onto passing a
+ * different `clover`/`hopping` pair in the descriptor.  The C++ facade in
+ * quantum-mg_amd/include/qmg/ rebuilds the reference class surface on top of this file;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - all complex data: interleaved (re,im) double == std::complex<double>
+ *  - layouts (reference README.md:4-11): vector (eo,y,x,c); matrix (eo,y,x,c1,c2) row-major;
+ *    hopping (mu,eo,y,x,c1,c2), mu in {+x,+y,-x,-y}; site i = (y + p*Ly)*Lx/2 + x/2
+ *  - Lx, Ly even and >= 2 (cshift_2d.h:62,79 step two rows at a time)
+ *  - extents are 64-bit internally (the reference's `int` size_hopping overflows at
+ *    1024^2 x 24^2 x 4, lattice.h:23,40)
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *    asynchronous on that stream unless stated otherwise
+ *  - return value: qmg_status (0 = success).  Nothing here falls back to the CPU: a call
+ *    that cannot run on the GPU returns an error.
+ */
+#ifndef QMG_HIP_H
+#define QMG_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  QMG_SUCCESS = 0,
+  QMG_ERR_INVALID = 1,      /* bad extents / NULL array / unsupported nc             */
+  QMG_ERR_HIP = 2,          /* a HIP runtime call failed (qmg_last_hip_error())      */
+  QMG_ERR_UNSUPPORTED = 3,  /* valid in the reference but not built yet              */
+  QMG_ERR_NO_DEVICE = 4
+} qmg_status;
+
+/* cshift directions / parities: values identical to cshift/cshift_2d.h:13-36 */
+enum { QMG_CSHIFT_FROM_0 = 1, QMG_CSHIFT_FROM_XP1 = 2, QMG_CSHIFT_FROM_YP1 = 3,
+       QMG_CSHIFT_FROM_XM1 = 4, QMG_CSHIFT_FROM_YM1 = 5 };
+enum { QMG_EO_FROM_EVEN = 1, QMG_EO_FROM_ODD = 2, QMG_EO_FROM_EVENODD = 3 };
+/* hopping direction index: stencil/stencil_2d.h:25-40 */
+enum { QMG_DIR_INDEX_XP1 = 0, QMG_DIR_INDEX_YP1 = 1, QMG_DIR_INDEX_XM1 = 2, QMG_DIR_INDEX_YM1 = 3 };
+
+/* Which pieces of  lhs (+)= M rhs  one fused launch applies.  Each reference method is one mask:
+ *   apply_M            (stencil_2d.h:912-936)  QMG_P_ALL
+ *   apply_M_clover     (:694-703)              QMG_P_CLOVER
+ *   apply_M_eo / _oe   (:706-802)              QMG_P_EO / QMG_P_OE      (even / odd OUTPUT sites)
+ *   ... one direction  (:736-841)              QMG_P_EO_XP1 << dir, QMG_P_OE_XP1 << dir
+ *   apply_M_shift      (:865-909)              QMG_P_SHIFT
+ *   apply_M_ee / _oo   (:666-692)              QMG_P_CLOVER_E|QMG_P_SHIFT_E with eo/dof shift zeroed
+ * QMG_P_ZERO_E/_O overwrite that half instead of accumulating into it (the C wrappers'
+ * zero_vector + apply, :2571-2576, in one pass).  A half with no bit set is not touched. */
+enum {
+  QMG_P_CLOVER_E = 1u << 0,  QMG_P_CLOVER_O = 1u << 1,
+  QMG_P_EO_XP1 = 1u << 2, QMG_P_EO_YP1 = 1u << 3, QMG_P_EO_XM1 = 1u << 4, QMG_P_EO_YM1 = 1u << 5,
+  QMG_P_OE_XP1 = 1u << 6, QMG_P_OE_YP1 = 1u << 7, QMG_P_OE_XM1 = 1u << 8, QMG_P_OE_YM1 = 1u << 9,
+  QMG_P_SHIFT_E = 1u << 10, QMG_P_SHIFT_O = 1u << 11,
+  QMG_P_ZERO_E = 1u << 12,  QMG_P_ZERO_O = 1u << 13,
+  QMG_P_CLOVER = 3u, QMG_P_EO = 0xFu << 2, QMG_P_OE = 0xFu << 6, QMG_P_HOPPING = 0xFFu << 2,
+  QMG_P_SHIFT = 3u << 10, QMG_P_ZERO = 3u << 12,
+  QMG_P_ALL = 0xFFFu
+};
+
+/* The public data of a Stencil2D (stencil_2d.h:148-177) as the kernels need it. */
+typedef struct {
+  int Lx, Ly, nc;
+  const void* clover;      /* device, Lx*Ly*nc*nc complex, or NULL (stencil has no clover)   */
+  const void* hopping;     /* device, 4*Lx*Ly*nc*nc complex, or NULL                         */
+  double shift[2];         /* identity shift (mass)                         (:170)           */
+  double eo_shift[2];      /* +even / -odd                                  (:173)           */
+  double dof_shift[2];     /* +top half / -bottom half of the dof, nc even  (:177)           */
+} qmg_stencil_desc;
+
+/* ---------------- runtime ---------------- */
+int qmg_init(int device);                       /* hipSetDevice + sanity; QMG_ERR_NO_DEVICE if none */
+int qmg_device_count(int* n);
+const char* qmg_status_string(int status);
+const char* qmg_last_hip_error(void);
+const char* qmg_version(void);
+int qmg_malloc(void** dev_ptr, size_t bytes);   /* replaces allocate_vector<T> for device arrays */
+int qmg_free(void* dev_ptr);
+int qmg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);  /* synchronous when stream == NULL */
+int qmg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int qmg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int qmg_memset_zero(void* dev_ptr, size_t bytes, void* stream);
+int qmg_stream_create(void** stream);
+int qmg_stream_destroy(void* stream);
+int qmg_stream_sync(void* stream);
+int qmg_event_create(void** ev);
+int qmg_event_destroy(void* ev);
+int qmg_event_record(void* ev, void* stream);
+int qmg_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+
+/* ---------------- cshift (cshift/cshift_2d.h:45-236) ---------------- */
+/* lhs(opposite half) = rhs(neighbour); dof complex numbers per site. */
+int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, int Ly, void* stream);
+
+/* ---------------- stencil apply (stencil/stencil_2d.h:666-936, 2418-2453, 2571-2716) ---------------- */
+/* lhs (+)= pieces(M) rhs, fused in one launch.  nrhs >= 1 independent right-hand sides stored
+ * `vec_stride` complex elements apart share one read of the stencil matrices (vec_stride is
+ * ignored for nrhs == 1).  lhs and rhs must not overlap, except that a call with only
+ * QMG_P_EO (or only QMG_P_OE) pieces may pass lhs == rhs: it reads one half and writes the
+ * other (the reference's in-place use, stencil_2d.h:1904, staggered.h:236). */
+int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                      int nrhs, size_t vec_stride, void* stream);
+
+/* ---------------- operator construction from U(1) links (device side) ---------------- */
+/* gauge: nc=1 LatticeGauge (mu,eo,y,x), 2*Lx*Ly complex. */
+int qmg_wilson_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, double wilson_coeff, void* stream); /* wilson.h:153-209 */
+int qmg_staggered_fill(void* hopping, const void* gauge, int Lx, int Ly, void* stream);                                /* staggered.h:50-72 */
+int qmg_laplace_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, void* stream);                    /* gaugedlaplace.h:45-68 */
+
+/* ---------------- stencil variants (device side) ---------------- */
+/* build_dagger_stencil (stencil_2d.h:1080-1139); also serves build_rbj_dagger_stencil (:1989-2060). */
+int qmg_build_dagger(void* dagger_clover, void* dagger_hopping, const void* clover, const void* hopping,
+                     int Lx, int Ly, int nc, void* stream);
+/* build_rbjacobi_stencil (stencil_2d.h:1452-1601): cinv = (clover + shifts)^-1, rb clover = 1,
+ * rb hopping_mu(x) = hopping_mu(x) . cinv(x+mu).  nc <= 32. */
+int qmg_build_rbjacobi(void* cinv, void* rb_clover, void* rb_hopping, const qmg_stencil_desc* d, void* stream);
+/* batched nc x nc conjugate transpose (cMATcopy_conjtrans_square) */
+int qmg_cmat_conjtrans(void* out, const void* in, size_t nsite, int nc, void* stream);
+
+/* ---------------- BLAS-1 on device vectors (the quantum-linalg leaves the path calls) ---------------- */
+/* n = number of complex elements; scalars are (re,im) pairs passed by value. */
+int qmg_zero_vector(void* x, size_t n, void* stream);
+int qmg_copy_vector(void* dst, const void* src, size_t n, void* stream);
+int qmg_cax(double ar, double ai, void* x, size_t n, void* stream);                                   /* x *= a            */
+int qmg_caxy(double ar, double ai, const void* x, void* y, size_t n, void* stream);                   /* y  = a x          */
+int qmg_caxpy(double ar, double ai, const void* x, void* y, size_t n, void* stream);                  /* y += a x          */
+int qmg_cxpy(const void* x, void* y, size_t n, void* stream);                                         /* y += x            */
+int qmg_cxpay(const void* x, double ar, double ai, void* y, size_t n, void* stream);                  /* y  = x + a y      */
+int qmg_caxpby(double ar, double ai, const void* x, double br, double bi, void* y, size_t n, void* stream);            /* y = a x + b y */
+int qmg_cxpyz(const void* x, const void* y, void* z, size_t n, void* stream);                         /* z  = x + y        */
+int qmg_caxpbyz(double ar, double ai, const void* x, double br, double bi, const void* y, void* z, size_t n, void* stream); /* z = a x + b y */
+/* y[site,c] = scale[c] * x[site,shuffle[c]]  (caxy_shuffle_pattern; gamma5 / sigma1 / chiral projections,
+ * wilson.h:74-143, coarse.h:498-657).  nc <= 64; scale/shuffle are HOST arrays of length nc. */
+int qmg_caxy_pattern(const double* scale, const int* shuffle, int nc, const void* x, void* y, size_t nsite, void* stream);
+/* complex Gaussian fill, unit variance per real component, counter-based (reproducible, layout-independent) */
+int qmg_gaussian(void* x, size_t n, unsigned long long seed, void* stream);
+
+/* ---------------- global reductions ---------------- */
+/* Two-stage (wavefront DPP + LDS block) deterministic reductions.  `out_dev` is a DEVICE buffer
+ * (1 double for real results, 2 for dot) written asynchronously; `out_host`, if non-NULL, receives a
+ * copy and makes the call synchronous.  Either may be NULL, not both. */
+int qmg_norm2sq(const void* x, size_t n, double* out_dev, double* out_host, void* stream);
+int qmg_dot(const void* x, const void* y, size_t n, double* out_dev, double* out_host, void* stream);   /* sum conj(x) y */
+int qmg_diffnorm2sq(const void* x, const void* y, size_t n, double* out_dev, double* out_host, void* stream);
+int qmg_norminf(const void* x, size_t n, double* out_dev, double* out_host, void* stream);
+/* k dot products <x_i, y>, i < k, in one pass over y (GCR orthogonalisation). xs: HOST array of k device pointers.
+ * out: 2k doubles. k <= 64. */
+int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* out_dev, double* out_host, void* stream);
+/* reductions/reductions.h:24-87: per-timeslice (per-y) norm2sq / dot. out: Ly (or 2*Ly) doubles. */
+int qmg_norm2sq_cv_timeslice(const void* cv, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream);
+int qmg_dot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream);
+
+/* ---------------- transfer (transfer/transfer.h) ---------------- */
+/* Null vectors are passed as the reference holds them: nvec fine vectors, vector-major
+ * (null_vectors[d][k], transfer.h:79), contiguous with stride fine_size_cv.  Blocks are the
+ * regular (fLx/cLx) x (fLy/cLy) rectangles of build_mapping (:410-448). */
+int qmg_prolong(const void* nullvecs, int nvec, const void* coarse, void* fine,
+                int fLx, int fLy, int fnc, int cLx, int cLy, int cnc, void* stream);     /* fine += P coarse   (:455-480) */
+int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
+                 int fLx, int fLy, int fnc, int cLx, int cLy, int cnc, void* stream);    /* coarse += R fine   (:487-511) */
+/* block_orthonormalize, one pass, in place (:514-607); cholesky (cLx*cLy*nvec*nvec complex) may be NULL. */
+int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
+                             void* cholesky, void* stream);
+
+/* ---------------- Galerkin coarse operator (operators/coarse.h:90-444) ---------------- */
+int qmg_coarse_build(void* coarse_clover, void* coarse_hopping, const qmg_stencil_desc* fine,
+                     const void* nullvecs, const void* restrict_vecs /* or NULL */,
+                     int cLx, int cLy, int cnc, void* stream);
+
+/* ---------------- tuning hooks (not part of the reference surface) ---------------- */
+/* key "stencil_nt": 1 = non-temporal loads for the stencil matrices in the nc<=4 kernel. */
+int qmg_set_tuning(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMG_HIP_H */

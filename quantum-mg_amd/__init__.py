@@ -1,0 +1,336 @@
+"""quantum-mg_amd -- MI355X-native multigrid hot path behind the quantum-mg operator API.
+
+The product is `libqmg_hip.so` (hand-written HIP kernels for gfx950 + a C-ABI, include/qmg_hip.h)
+and the C++ facade in `include/qmg/` that mirrors the reference's Stencil2D / TransferMG /
+StatefulMultigridMG classes.  This Python module is only the ctypes binding used by tests/,
+bench.py and __graft_entry__.py to drive the C-ABI; it holds no compute and has NO CPU
+fallback: if the shared library is missing, importing `lib()` raises.
+
+(The directory name contains a hyphen, so import it with
+ `importlib.import_module("quantum-mg_amd")`.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO_PATH = os.path.join(HERE, "libqmg_hip.so")
+
+# ---- enums (include/qmg_hip.h) ----
+P_CLOVER_E, P_CLOVER_O = 1 << 0, 1 << 1
+P_EO_XP1, P_OE_XP1 = 1 << 2, 1 << 6
+P_SHIFT_E, P_SHIFT_O = 1 << 10, 1 << 11
+P_ZERO_E, P_ZERO_O = 1 << 12, 1 << 13
+P_CLOVER, P_EO, P_OE, P_HOPPING = 3, 0xF << 2, 0xF << 6, 0xFF << 2
+P_SHIFT, P_ZERO, P_ALL = 3 << 10, 3 << 12, 0xFFF
+CSHIFT_FROM_0, CSHIFT_XP1, CSHIFT_YP1, CSHIFT_XM1, CSHIFT_YM1 = 1, 2, 3, 4, 5
+EO_FROM_EVEN, EO_FROM_ODD, EO_FROM_EVENODD = 1, 2, 3
+
+# every symbol include/qmg_hip.h declares (checked by tests/test_abi_symbols.py against the header text)
+ABI_SYMBOLS = [
+    "qmg_init", "qmg_device_count", "qmg_status_string", "qmg_last_hip_error", "qmg_version",
+    "qmg_malloc", "qmg_free", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
+    "qmg_stream_create", "qmg_stream_destroy", "qmg_stream_sync",
+    "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms",
+    "qmg_cshift", "qmg_stencil_apply", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
+    "qmg_build_dagger", "qmg_build_rbjacobi", "qmg_cmat_conjtrans",
+    "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",
+    "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_caxy_pattern", "qmg_gaussian",
+    "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
+    "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
+    "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
+]
+
+
+class StencilDesc(C.Structure):
+    _fields_ = [("Lx", C.c_int), ("Ly", C.c_int), ("nc", C.c_int),
+                ("clover", C.c_void_p), ("hopping", C.c_void_p),
+                ("shift", C.c_double * 2), ("eo_shift", C.c_double * 2), ("dof_shift", C.c_double * 2)]
+
+
+class QmgError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libqmg_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "-j4", "libqmg_hip.so"], stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise QmgError("libqmg_hip.so not built (%s); run __graft_entry__.build() -- there is no CPU fallback" % SO_PATH)
+        _lib = C.CDLL(SO_PATH)
+        _lib.qmg_status_string.restype = C.c_char_p
+        _lib.qmg_last_hip_error.restype = C.c_char_p
+        _lib.qmg_version.restype = C.c_char_p
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        L = lib()
+        raise QmgError("%s failed: %s [%s]" % (what or "qmg call", L.qmg_status_string(status).decode(), L.qmg_last_hip_error().decode()))
+
+
+def init(device=0):
+    check(lib().qmg_init(device), "qmg_init")
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().qmg_device_count(C.byref(n))
+    return n.value
+
+
+def sync(stream=None):
+    check(lib().qmg_stream_sync(C.c_void_p(stream)), "qmg_stream_sync")
+
+
+class DeviceArray:
+    """A complex128 (or raw bytes) array in HBM owned through qmg_malloc / qmg_free."""
+
+    def __init__(self, n, dtype=np.complex128):
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = self.n * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().qmg_malloc(C.byref(p), C.c_size_t(self.nbytes)), "qmg_malloc")
+        self.ptr = p.value or 0
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype)
+        check(lib().qmg_memcpy_h2d(C.c_void_p(d.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(d.nbytes), None), "h2d")
+        return d
+
+    @classmethod
+    def zeros(cls, n, dtype=np.complex128):
+        d = cls(n, dtype)
+        check(lib().qmg_memset_zero(C.c_void_p(d.ptr), C.c_size_t(d.nbytes), None), "memset")
+        return d
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        sync()
+        check(lib().qmg_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), None), "d2h")
+        return out
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size == self.n
+        check(lib().qmg_memcpy_h2d(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes), None), "h2d")
+
+    def offset(self, elems):
+        return self.ptr + int(elems) * self.dtype.itemsize
+
+    def free(self):
+        if self.ptr:
+            lib().qmg_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _vp(x):
+    if x is None:
+        return C.c_void_p(None)
+    if isinstance(x, DeviceArray):
+        return C.c_void_p(x.ptr)
+    return C.c_void_p(int(x))
+
+
+def make_desc(Lx, Ly, nc, clover, hopping, shift=0.0, eo_shift=0.0, dof_shift=0.0):
+    d = StencilDesc()
+    d.Lx, d.Ly, d.nc = Lx, Ly, nc
+    d.clover = None if clover is None else (clover.ptr if isinstance(clover, DeviceArray) else int(clover))
+    d.hopping = None if hopping is None else (hopping.ptr if isinstance(hopping, DeviceArray) else int(hopping))
+    for name, v in (("shift", shift), ("eo_shift", eo_shift), ("dof_shift", dof_shift)):
+        v = complex(v)
+        getattr(d, name)[0], getattr(d, name)[1] = v.real, v.imag
+    d._keep = (clover, hopping)
+    return d
+
+
+def stencil_apply(desc, lhs, rhs, pieces=P_ALL | P_ZERO, nrhs=1, vec_stride=0, stream=None):
+    check(lib().qmg_stencil_apply(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), C.c_int(nrhs),
+                                  C.c_size_t(vec_stride), C.c_void_p(stream)), "qmg_stencil_apply")
+
+
+def cshift(lhs, rhs, cdir, eo, dof, Lx, Ly, stream=None):
+    check(lib().qmg_cshift(_vp(lhs), _vp(rhs), cdir, eo, dof, Lx, Ly, C.c_void_p(stream)), "qmg_cshift")
+
+
+def wilson_fill(clover, hopping, gauge, Lx, Ly, w=1.0, stream=None):
+    check(lib().qmg_wilson_fill(_vp(clover), _vp(hopping), _vp(gauge), Lx, Ly, C.c_double(w), C.c_void_p(stream)), "qmg_wilson_fill")
+
+
+def staggered_fill(hopping, gauge, Lx, Ly, stream=None):
+    check(lib().qmg_staggered_fill(_vp(hopping), _vp(gauge), Lx, Ly, C.c_void_p(stream)), "qmg_staggered_fill")
+
+
+def laplace_fill(clover, hopping, gauge, Lx, Ly, stream=None):
+    check(lib().qmg_laplace_fill(_vp(clover), _vp(hopping), _vp(gauge), Lx, Ly, C.c_void_p(stream)), "qmg_laplace_fill")
+
+
+def build_dagger(dclover, dhopping, clover, hopping, Lx, Ly, nc, stream=None):
+    check(lib().qmg_build_dagger(_vp(dclover), _vp(dhopping), _vp(clover), _vp(hopping), Lx, Ly, nc, C.c_void_p(stream)), "qmg_build_dagger")
+
+
+def build_rbjacobi(cinv, rclover, rhopping, desc, stream=None):
+    check(lib().qmg_build_rbjacobi(_vp(cinv), _vp(rclover), _vp(rhopping), C.byref(desc), C.c_void_p(stream)), "qmg_build_rbjacobi")
+
+
+def _scalar(a):
+    a = complex(a)
+    return C.c_double(a.real), C.c_double(a.imag)
+
+
+def zero_vector(x, n):
+    check(lib().qmg_zero_vector(_vp(x), C.c_size_t(n), None))
+
+
+def copy_vector(dst, src, n):
+    check(lib().qmg_copy_vector(_vp(dst), _vp(src), C.c_size_t(n), None))
+
+
+def cax(a, x, n):
+    check(lib().qmg_cax(*_scalar(a), _vp(x), C.c_size_t(n), None))
+
+
+def caxy(a, x, y, n):
+    check(lib().qmg_caxy(*_scalar(a), _vp(x), _vp(y), C.c_size_t(n), None))
+
+
+def caxpy(a, x, y, n):
+    check(lib().qmg_caxpy(*_scalar(a), _vp(x), _vp(y), C.c_size_t(n), None))
+
+
+def cxpy(x, y, n):
+    check(lib().qmg_cxpy(_vp(x), _vp(y), C.c_size_t(n), None))
+
+
+def cxpay(x, a, y, n):
+    check(lib().qmg_cxpay(_vp(x), *_scalar(a), _vp(y), C.c_size_t(n), None))
+
+
+def caxpby(a, x, b, y, n):
+    check(lib().qmg_caxpby(*_scalar(a), _vp(x), *_scalar(b), _vp(y), C.c_size_t(n), None))
+
+
+def cxpyz(x, y, z, n):
+    check(lib().qmg_cxpyz(_vp(x), _vp(y), _vp(z), C.c_size_t(n), None))
+
+
+def caxpbyz(a, x, b, y, z, n):
+    check(lib().qmg_caxpbyz(*_scalar(a), _vp(x), *_scalar(b), _vp(y), _vp(z), C.c_size_t(n), None))
+
+
+def caxy_pattern(scale, shuffle, x, y, nsite):
+    nc = len(scale)
+    sc = (C.c_double * nc)(*scale)
+    sh = (C.c_int * nc)(*shuffle)
+    check(lib().qmg_caxy_pattern(sc, sh, nc, _vp(x), _vp(y), C.c_size_t(nsite), None))
+
+
+def gaussian(x, n, seed):
+    check(lib().qmg_gaussian(_vp(x), C.c_size_t(n), C.c_ulonglong(seed), None))
+
+
+def norm2sq(x, n):
+    out = C.c_double()
+    check(lib().qmg_norm2sq(_vp(x), C.c_size_t(n), None, C.byref(out), None))
+    return out.value
+
+
+def dot(x, y, n):
+    out = (C.c_double * 2)()
+    check(lib().qmg_dot(_vp(x), _vp(y), C.c_size_t(n), None, out, None))
+    return complex(out[0], out[1])
+
+
+def diffnorm2sq(x, y, n):
+    out = C.c_double()
+    check(lib().qmg_diffnorm2sq(_vp(x), _vp(y), C.c_size_t(n), None, C.byref(out), None))
+    return out.value
+
+
+def norminf(x, n):
+    out = C.c_double()
+    check(lib().qmg_norminf(_vp(x), C.c_size_t(n), None, C.byref(out), None))
+    return out.value
+
+
+def multidot(xs, y, n):
+    k = len(xs)
+    ptrs = (C.c_void_p * k)(*[(x.ptr if isinstance(x, DeviceArray) else int(x)) for x in xs])
+    out = (C.c_double * (2 * k))()
+    check(lib().qmg_multidot(ptrs, k, _vp(y), C.c_size_t(n), None, out, None))
+    return np.array([complex(out[2 * i], out[2 * i + 1]) for i in range(k)])
+
+
+def norm2sq_cv_timeslice(cv, Lx, Ly, nc):
+    out = np.zeros(Ly)
+    check(lib().qmg_norm2sq_cv_timeslice(_vp(cv), Lx, Ly, nc, None, out.ctypes.data_as(C.POINTER(C.c_double)), None))
+    return out
+
+
+def dot_cv_timeslice(a, b, Lx, Ly, nc):
+    out = np.zeros(2 * Ly)
+    check(lib().qmg_dot_cv_timeslice(_vp(a), _vp(b), Lx, Ly, nc, None, out.ctypes.data_as(C.POINTER(C.c_double)), None))
+    return out[0::2] + 1j * out[1::2]
+
+
+def prolong(nullvecs, nvec, coarse, fine, fdims, cdims):
+    check(lib().qmg_prolong(_vp(nullvecs), nvec, _vp(coarse), _vp(fine), *fdims, *cdims, None), "qmg_prolong")
+
+
+def restrict(nullvecs, nvec, fine, coarse, fdims, cdims):
+    check(lib().qmg_restrict(_vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, None), "qmg_restrict")
+
+
+def block_orthonormalize(nullvecs, nvec, fdims, cLx, cLy, cholesky=None):
+    check(lib().qmg_block_orthonormalize(_vp(nullvecs), nvec, *fdims, cLx, cLy, _vp(cholesky), None), "qmg_block_orthonormalize")
+
+
+def coarse_build(cclover, chopping, fdesc, nullvecs, cdims, restrict_vecs=None):
+    check(lib().qmg_coarse_build(_vp(cclover), _vp(chopping), C.byref(fdesc), _vp(nullvecs), _vp(restrict_vecs), *cdims, None), "qmg_coarse_build")
+
+
+def set_tuning(key, value):
+    check(lib().qmg_set_tuning(key.encode(), int(value)), "qmg_set_tuning")
+
+
+class Timer:
+    """HIP-event timing on the stream the kernels are launched on (NULL stream by default)."""
+
+    def __init__(self):
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        check(lib().qmg_event_create(C.byref(self.a)))
+        check(lib().qmg_event_create(C.byref(self.b)))
+
+    def start(self, stream=None):
+        check(lib().qmg_event_record(self.a, C.c_void_p(stream)))
+
+    def stop_ms(self, stream=None):
+        check(lib().qmg_event_record(self.b, C.c_void_p(stream)))
+        ms = C.c_float()
+        check(lib().qmg_event_elapsed_ms(self.a, self.b, C.byref(ms)))
+        return ms.value

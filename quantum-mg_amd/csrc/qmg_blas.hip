@@ -1,0 +1,370 @@
+// qmg_blas.hip -- device BLAS-1 leaves and global reductions of the multigrid hot path.
+//
+// The reference takes these from quantum-linalg (absent; semantics inferred from call sites,
+// SURVEY 2.2): caxpy/cxpay/caxpbyz/... are single streaming passes; norm2sq/dot/diffnorm2sq are
+// the Krylov inner products (stateful_multigrid.h:880,884,904 and every solver iteration).
+//
+// Reductions are two-stage and DETERMINISTIC: each lane accumulates a grid-strided slice in
+// fp64, a DPP/shuffle butterfly sums the wavefront, LDS sums the 4 wavefronts of the block,
+// the block writes one partial, and a second tiny launch sums the (fixed number of) partials
+// in a fixed order -- no float atomics, so two runs give bit-identical inner products.
+#include <string.h>
+
+#include "qmg_common.h"
+
+namespace qmg {
+
+constexpr int RED_BLOCKS = 1024;    // partials per reduction (4 blocks per CU)
+constexpr int RED_MAXK = 64;        // multidot width
+
+// ---------------- streaming BLAS-1 ----------------
+enum BlasOp { OP_ZERO, OP_COPY, OP_CAX, OP_CAXY, OP_CAXPY, OP_CXPY, OP_CXPAY, OP_CAXPBY, OP_CXPYZ, OP_CAXPBYZ };
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_blas(cplx* __restrict__ z, const cplx* __restrict__ x, const cplx* __restrict__ y,
+                                                cplx a, cplx b, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    cplx r;
+    if (OP == OP_ZERO) r = cmake(0.0, 0.0);
+    else if (OP == OP_COPY) r = x[i];
+    else if (OP == OP_CAX) r = cmul(a, z[i]);
+    else if (OP == OP_CAXY) r = cmul(a, x[i]);
+    else if (OP == OP_CAXPY) { r = z[i]; cmac(r, a, x[i]); }
+    else if (OP == OP_CXPY) r = cadd(z[i], x[i]);
+    else if (OP == OP_CXPAY) { r = x[i]; cmac(r, a, z[i]); }
+    else if (OP == OP_CAXPBY) { r = cmul(b, z[i]); cmac(r, a, x[i]); }
+    else if (OP == OP_CXPYZ) r = cadd(x[i], y[i]);
+    else { r = cmul(a, x[i]); cmac(r, b, y[i]); }
+    z[i] = r;
+  }
+}
+
+struct Pattern { double scale[64]; int shuffle[64]; };
+__global__ __launch_bounds__(BLOCK) void k_pattern(cplx* __restrict__ y, const cplx* __restrict__ x, long nsite, int nc, Pattern pat) {
+  const long n = nsite * nc;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long site = i / nc;
+    const int c = (int)(i - site * nc);
+    const cplx v = x[site * nc + pat.shuffle[c]];
+    y[i] = cmake(pat.scale[c] * v.x, pat.scale[c] * v.y);
+  }
+}
+
+// counter-based Gaussian: splitmix64 -> two uniforms -> Box-Muller; element i depends only on (seed, i)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(BLOCK) void k_gaussian(cplx* __restrict__ x, long n, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const unsigned long long h1 = splitmix64(seed * 0xD1342543DE82EF95ull + 2ull * (unsigned long long)i);
+    const unsigned long long h2 = splitmix64(h1 + 2ull * (unsigned long long)i + 1ull);
+    const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);   // (0,1]
+    const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    x[i] = cmake(rad * cs, rad * sn);
+  }
+}
+
+// ---------------- reductions ----------------
+enum RedOp { RED_NORM2, RED_DOT, RED_DIFFNORM2, RED_NORMINF };
+
+template <int NV, bool MAX>
+__device__ __forceinline__ void block_reduce_store(double* v, double* partial_out) {
+  __shared__ double sm[NV][BLOCK / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    const double w = MAX ? wave_max(v[q]) : wave_sum(v[q]);
+    if (lane == 0) sm[q][wv] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double t = sm[threadIdx.x][0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / WAVE; w++) t = MAX ? fmax(t, sm[threadIdx.x][w]) : t + sm[threadIdx.x][w];
+    partial_out[threadIdx.x] = t;
+  }
+}
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_reduce(const cplx* __restrict__ x, const cplx* __restrict__ y, long n, double* __restrict__ partials) {
+  double v[2] = {0.0, 0.0};
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const cplx a = x[i];
+    if (OP == RED_NORM2) { v[0] = fma(a.x, a.x, v[0]); v[0] = fma(a.y, a.y, v[0]); }
+    else if (OP == RED_DOT) {
+      const cplx b = y[i];
+      v[0] = fma(a.x, b.x, v[0]); v[0] = fma(a.y, b.y, v[0]);
+      v[1] = fma(a.x, b.y, v[1]); v[1] = fma(-a.y, b.x, v[1]);
+    } else if (OP == RED_DIFFNORM2) {
+      const cplx b = y[i];
+      const double dx = a.x - b.x, dy = a.y - b.y;
+      v[0] = fma(dx, dx, v[0]); v[0] = fma(dy, dy, v[0]);
+    } else {
+      v[0] = fmax(v[0], a.x * a.x + a.y * a.y);
+    }
+  }
+  block_reduce_store<2, OP == RED_NORMINF>(v, partials + 2 * blockIdx.x);
+}
+
+// stage 2: one block sums nparts partials of width `width` in a fixed order
+template <bool MAX, bool SQRT>
+__global__ __launch_bounds__(BLOCK) void k_reduce_final(const double* __restrict__ partials, int nparts, int stride, int width, double* __restrict__ out) {
+  __shared__ double sm[BLOCK];
+  for (int q = 0; q < width; q++) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += BLOCK) t = MAX ? fmax(t, partials[(long)i * stride + q]) : t + partials[(long)i * stride + q];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sm[threadIdx.x] = MAX ? fmax(sm[threadIdx.x], sm[threadIdx.x + s]) : sm[threadIdx.x] + sm[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[q] = SQRT ? sqrt(sm[0]) : sm[0];
+    __syncthreads();
+  }
+}
+
+struct MultiPtrs { const cplx* x[RED_MAXK]; };
+// k dots <x_i, y> in one pass over y: y[i] is loaded once per element and reused for all k vectors.
+template <int KT>
+__global__ __launch_bounds__(BLOCK) void k_multidot(MultiPtrs xs, int k0, const cplx* __restrict__ y, long n, double* __restrict__ partials, int ktot) {
+  double v[2 * KT];
+#pragma unroll
+  for (int q = 0; q < 2 * KT; q++) v[q] = 0.0;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const cplx b = y[i];
+#pragma unroll
+    for (int q = 0; q < KT; q++) {
+      const cplx a = xs.x[k0 + q][i];
+      v[2 * q] = fma(a.x, b.x, v[2 * q]); v[2 * q] = fma(a.y, b.y, v[2 * q]);
+      v[2 * q + 1] = fma(a.x, b.y, v[2 * q + 1]); v[2 * q + 1] = fma(-a.y, b.x, v[2 * q + 1]);
+    }
+  }
+  block_reduce_store<2 * KT, false>(v, partials + (long)blockIdx.x * 2 * ktot + 2 * k0);
+}
+
+// per-timeslice reductions (reductions/reductions.h:24-87): sum over x and c for each y.
+// In the even-odd layout row y is two contiguous runs (one per parity) of hr*nc elements.
+template <bool DOT>
+__global__ __launch_bounds__(BLOCK) void k_timeslice(const cplx* __restrict__ a, const cplx* __restrict__ b, int hr, int Ly, int nc, double* __restrict__ out) {
+  const int y = blockIdx.x;
+  const long half_cv = (long)hr * Ly * nc;
+  const long run = (long)hr * nc;
+  double v[2] = {0.0, 0.0};
+  for (int p = 0; p < 2; p++) {
+    const cplx* ap = a + p * half_cv + (long)y * run;
+    const cplx* bp = DOT ? b + p * half_cv + (long)y * run : nullptr;
+    for (long i = threadIdx.x; i < run; i += BLOCK) {
+      const cplx u = ap[i];
+      if (DOT) {
+        const cplx w = bp[i];
+        v[0] = fma(u.x, w.x, v[0]); v[0] = fma(u.y, w.y, v[0]);
+        v[1] = fma(u.x, w.y, v[1]); v[1] = fma(-u.y, w.x, v[1]);
+      } else { v[0] = fma(u.x, u.x, v[0]); v[0] = fma(u.y, u.y, v[0]); }
+    }
+  }
+  double part[2];
+  __shared__ double res[2];
+  block_reduce_store<2, false>(v, res);
+  __syncthreads();
+  part[0] = res[0]; part[1] = res[1];
+  if (threadIdx.x == 0) {
+    if (DOT) { out[2 * y] = part[0]; out[2 * y + 1] = part[1]; }
+    else out[y] = part[0];
+  }
+}
+
+// Per-device workspace for partials and the default result slot.
+struct RedWorkspace {
+  double* partials = nullptr;   // RED_BLOCKS * 2 * RED_MAXK doubles
+  double* result = nullptr;     // 2 * RED_MAXK doubles
+  int device = -1;
+};
+static thread_local RedWorkspace g_ws;
+
+static int get_ws(RedWorkspace** out) {
+  int dev = 0;
+  QMG_HIP_CHECK(hipGetDevice(&dev));
+  if (g_ws.device != dev) {
+    // (leaks the previous device's few hundred KB if a thread hops devices; one rank = one device here)
+    QMG_HIP_CHECK(hipMalloc((void**)&g_ws.partials, sizeof(double) * RED_BLOCKS * 2 * RED_MAXK));
+    QMG_HIP_CHECK(hipMalloc((void**)&g_ws.result, sizeof(double) * 2 * RED_MAXK));
+    g_ws.device = dev;
+  }
+  *out = &g_ws;
+  return QMG_SUCCESS;
+}
+
+static unsigned red_grid(long n) {
+  long b = (n + BLOCK - 1) / BLOCK;
+  if (b > RED_BLOCKS) b = RED_BLOCKS;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+static int finish(double* result_dev, int width, double* out_dev, double* out_host, hipStream_t st) {
+  if (out_dev && out_dev != result_dev)
+    QMG_HIP_CHECK(hipMemcpyAsync(out_dev, result_dev, sizeof(double) * width, hipMemcpyDeviceToDevice, st));
+  if (out_host) {
+    QMG_HIP_CHECK(hipMemcpyAsync(out_host, result_dev, sizeof(double) * width, hipMemcpyDeviceToHost, st));
+    QMG_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  return QMG_SUCCESS;
+}
+
+template <int OP>
+static int reduce2(const void* x, const void* y, size_t n, int width, double* out_dev, double* out_host, void* stream) {
+  if (!x || (!out_dev && !out_host)) return QMG_ERR_INVALID;
+  if ((OP == RED_DOT || OP == RED_DIFFNORM2) && !y) return QMG_ERR_INVALID;
+  RedWorkspace* ws;
+  int rc = get_ws(&ws);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const unsigned g = red_grid((long)n);
+  k_reduce<OP><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
+  QMG_LAUNCH_CHECK();
+  double* res = out_dev ? out_dev : ws->result;
+  if (OP == RED_NORMINF) k_reduce_final<true, true><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
+  else k_reduce_final<false, false><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
+  QMG_LAUNCH_CHECK();
+  return finish(res, width, nullptr, out_host, st);
+}
+
+template <int OP>
+static int blas_launch(void* z, const void* x, const void* y, cplx a, cplx b, size_t n, void* stream) {
+  if (n == 0) return QMG_SUCCESS;
+  k_blas<OP><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((cplx*)z, (const cplx*)x, (const cplx*)y, a, b, (long)n);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+}  // namespace qmg
+
+using namespace qmg;
+
+extern "C" {
+
+int qmg_zero_vector(void* x, size_t n, void* s) {
+  if (!x && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_ZERO>(x, nullptr, nullptr, make_double2(0, 0), make_double2(0, 0), n, s);
+}
+int qmg_copy_vector(void* dst, const void* src, size_t n, void* s) {
+  if ((!dst || !src) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_COPY>(dst, src, nullptr, make_double2(0, 0), make_double2(0, 0), n, s);
+}
+int qmg_cax(double ar, double ai, void* x, size_t n, void* s) {
+  if (!x && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CAX>(x, nullptr, nullptr, make_double2(ar, ai), make_double2(0, 0), n, s);
+}
+int qmg_caxy(double ar, double ai, const void* x, void* y, size_t n, void* s) {
+  if ((!x || !y) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CAXY>(y, x, nullptr, make_double2(ar, ai), make_double2(0, 0), n, s);
+}
+int qmg_caxpy(double ar, double ai, const void* x, void* y, size_t n, void* s) {
+  if ((!x || !y) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CAXPY>(y, x, nullptr, make_double2(ar, ai), make_double2(0, 0), n, s);
+}
+int qmg_cxpy(const void* x, void* y, size_t n, void* s) {
+  if ((!x || !y) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CXPY>(y, x, nullptr, make_double2(0, 0), make_double2(0, 0), n, s);
+}
+int qmg_cxpay(const void* x, double ar, double ai, void* y, size_t n, void* s) {
+  if ((!x || !y) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CXPAY>(y, x, nullptr, make_double2(ar, ai), make_double2(0, 0), n, s);
+}
+int qmg_caxpby(double ar, double ai, const void* x, double br, double bi, void* y, size_t n, void* s) {
+  if ((!x || !y) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CAXPBY>(y, x, nullptr, make_double2(ar, ai), make_double2(br, bi), n, s);
+}
+int qmg_cxpyz(const void* x, const void* y, void* z, size_t n, void* s) {
+  if ((!x || !y || !z) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CXPYZ>(z, x, y, make_double2(0, 0), make_double2(0, 0), n, s);
+}
+int qmg_caxpbyz(double ar, double ai, const void* x, double br, double bi, const void* y, void* z, size_t n, void* s) {
+  if ((!x || !y || !z) && n) return QMG_ERR_INVALID;
+  return blas_launch<OP_CAXPBYZ>(z, x, y, make_double2(ar, ai), make_double2(br, bi), n, s);
+}
+
+int qmg_caxy_pattern(const double* scale, const int* shuffle, int nc, const void* x, void* y, size_t nsite, void* s) {
+  if (!scale || !shuffle || nc < 1 || nc > 64 || !x || !y || x == y) return QMG_ERR_INVALID;
+  Pattern pat;
+  for (int c = 0; c < nc; c++) {
+    if (shuffle[c] < 0 || shuffle[c] >= nc) return QMG_ERR_INVALID;
+    pat.scale[c] = scale[c];
+    pat.shuffle[c] = shuffle[c];
+  }
+  if (nsite == 0) return QMG_SUCCESS;
+  k_pattern<<<grid_1d(nsite * nc), BLOCK, 0, as_stream(s)>>>((cplx*)y, (const cplx*)x, (long)nsite, nc, pat);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+int qmg_gaussian(void* x, size_t n, unsigned long long seed, void* s) {
+  if (!x && n) return QMG_ERR_INVALID;
+  if (n == 0) return QMG_SUCCESS;
+  k_gaussian<<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)x, (long)n, seed);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+int qmg_norm2sq(const void* x, size_t n, double* od, double* oh, void* s) { return reduce2<RED_NORM2>(x, nullptr, n, 1, od, oh, s); }
+int qmg_dot(const void* x, const void* y, size_t n, double* od, double* oh, void* s) { return reduce2<RED_DOT>(x, y, n, 2, od, oh, s); }
+int qmg_diffnorm2sq(const void* x, const void* y, size_t n, double* od, double* oh, void* s) { return reduce2<RED_DIFFNORM2>(x, y, n, 1, od, oh, s); }
+int qmg_norminf(const void* x, size_t n, double* od, double* oh, void* s) { return reduce2<RED_NORMINF>(x, nullptr, n, 1, od, oh, s); }
+
+int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* out_dev, double* out_host, void* stream) {
+  if (!xs || !y || k < 1 || k > RED_MAXK || (!out_dev && !out_host)) return QMG_ERR_INVALID;
+  RedWorkspace* ws;
+  int rc = get_ws(&ws);
+  if (rc) return rc;
+  MultiPtrs mp;
+  for (int i = 0; i < k; i++) { if (!xs[i]) return QMG_ERR_INVALID; mp.x[i] = (const cplx*)xs[i]; }
+  hipStream_t st = as_stream(stream);
+  const unsigned g = red_grid((long)n);
+  int k0 = 0;
+  while (k0 < k) {   // chunks of 4 / 2 / 1 vectors: y is re-read once per chunk
+    const int rem = k - k0;
+    if (rem >= 4) { k_multidot<4><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 4; }
+    else if (rem >= 2) { k_multidot<2><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 2; }
+    else { k_multidot<1><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 1; }
+    QMG_LAUNCH_CHECK();
+  }
+  double* res = out_dev ? out_dev : ws->result;
+  k_reduce_final<false, false><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2 * k, 2 * k, res);
+  QMG_LAUNCH_CHECK();
+  return finish(res, 2 * k, nullptr, out_host, st);
+}
+
+int qmg_norm2sq_cv_timeslice(const void* cv, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream) {
+  if (!cv || !valid_lattice(Lx, Ly) || nc < 1 || (!out_dev && !out_host)) return QMG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  double* res = out_dev;
+  double* tmp = nullptr;
+  if (!res) { QMG_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * Ly)); res = tmp; }
+  k_timeslice<false><<<Ly, BLOCK, 0, st>>>((const cplx*)cv, nullptr, Lx / 2, Ly, nc, res);
+  QMG_LAUNCH_CHECK();
+  int rc = finish(res, Ly, nullptr, out_host, st);
+  if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
+  return rc;
+}
+
+int qmg_dot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream) {
+  if (!a || !b || !valid_lattice(Lx, Ly) || nc < 1 || (!out_dev && !out_host)) return QMG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  double* res = out_dev;
+  double* tmp = nullptr;
+  if (!res) { QMG_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * 2 * Ly)); res = tmp; }
+  k_timeslice<true><<<Ly, BLOCK, 0, st>>>((const cplx*)a, (const cplx*)b, Lx / 2, Ly, nc, res);
+  QMG_LAUNCH_CHECK();
+  int rc = finish(res, 2 * Ly, nullptr, out_host, st);
+  if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// qmg_stencil.hip -- fused even-odd stencil apply for gfx950 (MI355X).
+//
+// Replaces the reference's un-fused pass structure
+//     apply_M = clover sweep + 8 x {cshift copy, cMATxpy sweep} + 2 x caxpy      (stencil_2d.h:912-936)
+// (~27 vector passes + 5 matrix passes) with ONE launch that reads every stencil
+// matrix once, the right-hand side once (from HBM; neighbours come back out of L2) and writes
+// the result once: 5 nc^2 c + 2 nc c bytes per site, the algorithmic minimum.
+//
+// Addressing (derived from lattice.h:75-81,204 and the loops of cshift_2d.h:60-119,149-210):
+// an output site of parity p on row y at half-row column j has x = 2j + s, s = (y+p)&1, and its
+// four neighbours live in the OPPOSITE parity half at
+//     +x: (y, j+s)   -x: (y, j+s-1)   +y: (y+1, j)   -y: (y-1, j)        (periodic)
+// The matrix multiplying a neighbour is stored at the OUTPUT site (stencil_2d.h:718-732), so a
+// lane streams five arrays at one common offset.
+//
+// Kernel A (nc = 1, 2, 4): "element per lane".  nc^2 adjacent lanes own one site; lane (r,c)
+// loads element M[r][c] of each of the five matrices, so every matrix load instruction of a
+// wavefront is one fully coalesced 1 KiB segment (16 B per lane) -- the AoS (c1,c2)-fastest
+// layout of the reference is already lane-contiguous and is NOT repacked.  The sum over c is a
+// DPP quad-permute (no LDS).  Rows of both parities are interleaved in block order, so the
+// even- and odd-output rows that share right-hand-side data run back to back on the same XCD
+// (blocks per row is a multiple of 8 for power-of-two lattices) and the second use hits L2.
+//
+// Kernel B (any nc, used for the Galerkin coarse operators): see below.
+
+#include <string.h>
+
+#include "qmg_common.h"
+
+namespace qmg {
+
+struct StencilArgs {
+  const cplx* clover;
+  const cplx* hopping;
+  cplx* lhs;
+  const cplx* rhs;
+  int hr;            // Lx / 2: sites per half row
+  int Ly;
+  long half_vol;     // sites per parity
+  long size_cm;      // complex elements per matrix field (both parities)
+  unsigned pieces;
+  int nrhs;
+  long vec_stride;   // complex elements between right-hand sides
+  int par_first;     // first parity processed
+  int par_count;     // 1 or 2 (2: rows interleaved even/odd)
+  int nrows;         // Ly * par_count
+  double shift[2], eo_shift[2], dof_shift[2];
+};
+
+template <bool NT>
+__device__ __forceinline__ cplx ld(const cplx* p) {
+  if (NT) {
+    cplx v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  }
+  return *p;
+}
+
+template <int NC, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
+  constexpr int E = NC * NC;
+  const int e = threadIdx.x % E;
+  const int r = e / NC, c = e % NC;
+  const int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
+  if (j >= a.hr) return;   // whole site groups leave together (E divides BLOCK)
+
+  for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
+    const int y = (a.par_count == 2) ? (row >> 1) : row;
+    const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
+    const unsigned hop_mask = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
+    const bool do_shift = (a.pieces >> (10 + p)) & 1u;
+    const bool do_zero = (a.pieces >> (12 + p)) & 1u;
+
+    const long site = (long)p * a.half_vol + (long)y * a.hr + j;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const int s = (y + p) & 1;
+    int jp = j + s;     if (jp == a.hr) jp = 0;
+    int jm = j + s - 1; if (jm < 0) jm = a.hr - 1;
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
+    const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+    long nb[4];
+    nb[0] = opp + (long)y * a.hr + jp;
+    nb[1] = opp + (long)yp * a.hr + j;
+    nb[2] = opp + (long)y * a.hr + jm;
+    nb[3] = opp + (long)ym * a.hr + j;
+
+    // Stencil matrices: one coalesced 16-byte element per lane per matrix; kept in registers
+    // across all right-hand sides.
+    cplx m[5];
+    m[4] = do_clover ? ld<NT>(a.clover + site * E + e) : cmake(0.0, 0.0);
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+      m[d] = ((hop_mask >> d) & 1u) ? ld<NT>(a.hopping + (long)d * a.size_cm + site * E + e) : cmake(0.0, 0.0);
+
+    // shift coefficient on the diagonal: shift +- eo_shift +- dof_shift (stencil_2d.h:890-908)
+    cplx sh = cmake(0.0, 0.0);
+    if (do_shift && r == c) {
+      const double sg = p ? -1.0 : 1.0;
+      const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+      sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
+                 a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+    }
+    const bool need_own = do_clover || do_shift;
+
+    for (int k = 0; k < a.nrhs; k++) {
+      const cplx* x = a.rhs + (long)k * a.vec_stride;
+      cplx* out = a.lhs + (long)k * a.vec_stride;
+      cplx xv[5];
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+        xv[d] = ((hop_mask >> d) & 1u) ? x[nb[d] * NC + c] : cmake(0.0, 0.0);
+      xv[4] = need_own ? x[site * NC + c] : cmake(0.0, 0.0);
+
+      cplx acc = cmake(0.0, 0.0);
+      cmac(acc, m[4], xv[4]);                       // clover first, as the reference does
+#pragma unroll
+      for (int d = 0; d < 4; d++) cmac(acc, m[d], xv[d]);
+      cmac(acc, sh, xv[4]);
+
+      if (NC >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
+      if (NC >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
+
+      if (c == 0) {
+        if (!do_zero) acc = cadd(out[site * NC + r], acc);
+        out[site * NC + r] = acc;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel B: any nc (coarse operators, nc = 8, 24, ...).  One block owns S consecutive sites of
+// one row.  Per piece (clover, 4 directions) the block copies the S matrices (S nc^2 x 16 B,
+// contiguous in the reference layout) global -> registers -> LDS with fully coalesced 16-byte
+// loads, software-pipelined one piece ahead, and the S neighbour vectors likewise.  Thread
+// (s, r, h) then accumulates the h-th slice of sum_c M[s][r][c] x[s][c] out of LDS (rows padded
+// by one element when nc is even so that 16 lanes of a ds_read_b128 hit 64 distinct banks), the
+// H slices are summed through LDS, and one thread per (s, r) writes the result.
+// The operation is HBM-bound (AI ~ 0.5 flop/B for one right-hand side): all that
+// matters is that the matrix stream is coalesced and deep enough in flight.
+// ------------------------------------------------------------------------------------------
+struct GenLayout {
+  int S;        // sites per block
+  int H;        // c-slices per row
+  int rs;       // padded LDS row stride (complex elements)
+  int mat_elems;   // S * nc * nc
+  int per_thread;  // ceil(mat_elems / BLOCK)
+};
+
+constexpr int GEN_MAX_PER_THREAD = 12;   // register-staged matrix elements per thread per piece
+
+template <int PT>
+__global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, const int nc, const GenLayout L) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  cplx* mlds = reinterpret_cast<cplx*>(smem_raw);                    // [S*nc rows][rs]
+  cplx* xlds = mlds + (size_t)L.S * nc * L.rs;                        // [S][nc]
+  cplx* red = xlds + (size_t)L.S * nc;                                // [H][S*nc]
+
+  const int tid = threadIdx.x;
+  const int rows = L.S * nc;             // (s, r) pairs in this block
+  const int h = tid / rows;              // slice id (threads beyond H*rows idle in the compute phase)
+  const int sr = tid - h * rows;
+  const bool worker = h < L.H;
+  const int s_of = sr / nc;
+  const int r_of = sr - s_of * nc;
+  const int cchunk = (nc + L.H - 1) / L.H;
+  const int c0 = h * cchunk;
+  const int c1 = (c0 + cchunk < nc) ? c0 + cchunk : nc;
+
+  const int j0 = blockIdx.x * L.S;
+  const int nsite = (a.hr - j0 < L.S) ? a.hr - j0 : L.S;    // ragged last tile
+  const long nc2 = (long)nc * nc;
+
+  for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
+    const int y = (a.par_count == 2) ? (row >> 1) : row;
+    const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
+    const unsigned hop_mask = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
+    const bool do_shift = (a.pieces >> (10 + p)) & 1u;
+    const bool do_zero = (a.pieces >> (12 + p)) & 1u;
+    const unsigned piece_mask = hop_mask | (do_clover ? 16u : 0u);   // bit 4 = clover
+
+    const long site0 = (long)p * a.half_vol + (long)y * a.hr + j0;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const int s = (y + p) & 1;
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
+    const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+
+    for (int k = 0; k < a.nrhs; k++) {
+      const cplx* x = a.rhs + (long)k * a.vec_stride;
+      cplx* out = a.lhs + (long)k * a.vec_stride;
+      cplx acc = cmake(0.0, 0.0);
+
+      // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
+      const int order[5] = {4, 0, 1, 2, 3};
+      cplx stage[PT];
+      cplx xstage = cmake(0.0, 0.0);
+      int cur = -1;
+      // find first active piece and prefetch it
+      int oi = 0;
+      while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
+      auto prefetch = [&](int piece) {
+        const cplx* msrc = (piece == 4) ? a.clover + site0 * nc2 : a.hopping + (long)piece * a.size_cm + site0 * nc2;
+        const int lim = nsite * (int)nc2;
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+          const int el = tid + q * BLOCK;
+          stage[q] = (el < lim) ? msrc[el] : cmake(0.0, 0.0);
+        }
+        // neighbour vector element for (site, c) = tid / nc, tid % nc
+        if (tid < nsite * nc) {
+          const int sl = tid / nc, cc = tid - sl * nc;
+          const int j = j0 + sl;
+          long nbsite;
+          if (piece == 4) nbsite = site0 + sl;
+          else if (piece == 0) { int jp = j + s; if (jp == a.hr) jp = 0; nbsite = opp + (long)y * a.hr + jp; }
+          else if (piece == 1) nbsite = opp + (long)yp * a.hr + j;
+          else if (piece == 2) { int jm = j + s - 1; if (jm < 0) jm = a.hr - 1; nbsite = opp + (long)y * a.hr + jm; }
+          else nbsite = opp + (long)ym * a.hr + j;
+          xstage = x[nbsite * nc + cc];
+        }
+      };
+      if (oi < 5) { cur = order[oi]; prefetch(cur); }
+
+      while (cur >= 0) {
+        __syncthreads();   // previous compute finished reading LDS
+        // registers -> LDS (padded rows)
+#pragma unroll
+        for (int q = 0; q < PT; q++) {
+          const int el = tid + q * BLOCK;
+          if (el < L.mat_elems) {
+            const int rowi = el / nc, cc = el - rowi * nc;
+            mlds[(size_t)rowi * L.rs + cc] = stage[q];
+          }
+        }
+        if (tid < L.S * nc) xlds[tid] = xstage;
+        // issue the next piece's global loads before computing on this one
+        int nxt = -1;
+        oi++;
+        while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
+        if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
+        __syncthreads();
+        if (worker && s_of < nsite) {
+          const cplx* mrow = mlds + (size_t)sr * L.rs;
+          const cplx* xs = xlds + s_of * nc;
+          for (int cc = c0; cc < c1; cc++) cmac(acc, mrow[cc], xs[cc]);
+        }
+        cur = nxt;
+      }
+
+      // shift term needs the own-site vector
+      if (do_shift && worker && h == 0 && s_of < nsite) {
+        const double sg = p ? -1.0 : 1.0;
+        const double dg = (nc % 2 == 0) ? ((r_of < nc / 2) ? 1.0 : -1.0) : 0.0;
+        const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
+                              a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+        cmac(acc, sh, x[(site0 + s_of) * nc + r_of]);
+      }
+      // sum the H slices
+      __syncthreads();
+      if (worker) red[(size_t)h * rows + sr] = acc;
+      __syncthreads();
+      if (h == 0 && s_of < nsite) {
+        cplx t = red[sr];
+        for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
+        const long o = (site0 + s_of) * nc + r_of;
+        if (!do_zero) t = cadd(out[o], t);
+        out[o] = t;
+      }
+    }
+  }
+}
+
+static int g_stencil_nt = 0;   // tuning knob: non-temporal matrix loads in kernel A
+
+static GenLayout make_gen_layout(int nc, int hr) {
+  GenLayout L;
+  const int nc2 = nc * nc;
+  int S = (BLOCK * GEN_MAX_PER_THREAD) / nc2;       // registers: S*nc^2 <= 256*12
+  if (S > BLOCK / nc) S = BLOCK / nc;               // one (s,r) row per thread at least
+  if (S > hr) S = hr;
+  if (S < 1) S = 1;
+  L.S = S;
+  int H = BLOCK / (S * nc);
+  if (H < 1) H = 1;
+  if (H > nc) H = nc;
+  L.H = H;
+  L.rs = nc + ((nc % 2 == 0) ? 1 : 0);
+  L.mat_elems = S * nc2;
+  L.per_thread = (L.mat_elems + BLOCK - 1) / BLOCK;
+  return L;
+}
+
+}  // namespace qmg
+
+using namespace qmg;
+
+extern "C" int qmg_set_tuning(const char* key, int value) {
+  if (!key) return QMG_ERR_INVALID;
+  if (!strcmp(key, "stencil_nt")) { g_stencil_nt = value; return QMG_SUCCESS; }
+  return QMG_ERR_INVALID;
+}
+
+extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                                 int nrhs, size_t vec_stride, void* stream) {
+  if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
+  if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
+  const int nc = d->nc;
+  if (nrhs > 1 && vec_stride < (size_t)d->Lx * d->Ly * nc) return QMG_ERR_INVALID;
+
+  StencilArgs a;
+  a.clover = (const cplx*)d->clover;
+  a.hopping = (const cplx*)d->hopping;
+  a.lhs = (cplx*)lhs;
+  a.rhs = (const cplx*)rhs;
+  a.hr = d->Lx / 2;
+  a.Ly = d->Ly;
+  a.half_vol = (long)a.hr * d->Ly;
+  a.size_cm = 2 * a.half_vol * nc * nc;
+  a.pieces = pieces;
+  a.nrhs = nrhs;
+  a.vec_stride = (long)vec_stride;
+  for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
+
+  // which parity halves have any work
+  const unsigned even_bits = QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E;
+  const unsigned odd_bits = QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O;
+  const bool ev = pieces & even_bits, od = pieces & odd_bits;
+  if (!ev && !od) return QMG_SUCCESS;
+  a.par_first = ev ? 0 : 1;
+  a.par_count = (ev && od) ? 2 : 1;
+  a.nrows = d->Ly * a.par_count;
+  const unsigned gy = a.nrows > 65535 ? 65535u : (unsigned)a.nrows;
+  hipStream_t st = as_stream(stream);
+
+  if (nc == 1 || nc == 2 || nc == 4) {
+    const int E = nc * nc;
+    const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
+    dim3 grid(gx, gy), block(BLOCK);
+    const bool nt = g_stencil_nt != 0;
+    if (nc == 1) { if (nt) k_stencil_elem<1, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<1, false><<<grid, block, 0, st>>>(a); }
+    if (nc == 2) { if (nt) k_stencil_elem<2, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<2, false><<<grid, block, 0, st>>>(a); }
+    if (nc == 4) { if (nt) k_stencil_elem<4, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<4, false><<<grid, block, 0, st>>>(a); }
+    QMG_LAUNCH_CHECK();
+    return QMG_SUCCESS;
+  }
+
+  if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
+  const GenLayout L = make_gen_layout(nc, a.hr);
+  if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
+  const size_t smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)L.S * nc + (size_t)L.H * L.S * nc);
+  if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
+  const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
+  dim3 grid(gx, gy), block(BLOCK);
+#define QMG_GEN_CASE(PT)                                                                                \
+  case PT:                                                                                              \
+    if (smem > 64 * 1024)                                                                               \
+      QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    k_stencil_gen<PT><<<grid, block, smem, st>>>(a, nc, L);                                            \
+    break;
+  switch (L.per_thread) {
+    QMG_GEN_CASE(1) QMG_GEN_CASE(2) QMG_GEN_CASE(3) QMG_GEN_CASE(4) QMG_GEN_CASE(5) QMG_GEN_CASE(6)
+    QMG_GEN_CASE(7) QMG_GEN_CASE(8) QMG_GEN_CASE(9) QMG_GEN_CASE(10) QMG_GEN_CASE(11) QMG_GEN_CASE(12)
+    default: return QMG_ERR_UNSUPPORTED;
+  }
+#undef QMG_GEN_CASE
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
