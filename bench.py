@@ -200,11 +200,18 @@ def main():
         "config": {"workload": "Wilson apply_stencil_2D_M, %dx%d U(1) (l64t64b60 tiled), nc=2, fp64, 1 rhs per GPU" % (L, L),
                    "lattice": [L, L], "nc": 2, "mass": MASS, "rhs_per_gpu": 1, "parallelism": "independent rhs per GPU, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_stencil_elem<2>", "algorithmic_bytes_per_launch": BYTES_PER_SITE * sites,
+                     "traffic": None, "kernel": "k_stencil_pair<2,2>", "algorithmic_bytes_per_launch": BYTES_PER_SITE * sites,
                      "avg_launch_ms": kern_ms},
         "hbm_gb_per_s_aggregate": world * BYTES_PER_SITE * sites * args.steps / wall / 1e9,
         "parity_gate_rel_l2": gate_err,
     }
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/),
+    # collected separately because counters cannot be read from inside the timed run.
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if L == 4096 and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        out["roofline"]["traffic"] = pmc["hbm_traffic_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 gfx950 correction)"
     wl.free()
 
     if rank == 0 and world == 1 and not args.no_also and L != 2048:

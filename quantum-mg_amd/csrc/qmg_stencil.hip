@@ -45,6 +45,7 @@ struct StencilArgs {
   int par_count;     // 1 or 2 (2: rows interleaved even/odd)
   int nrows;         // Ly * par_count
   double shift[2], eo_shift[2], dof_shift[2];
+  int ablate;        // diagnostic builds only (tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 };
 
 template <bool NT>
@@ -58,7 +59,17 @@ __device__ __forceinline__ cplx ld(const cplx* p) {
   return *p;
 }
 
-template <int NC, bool NT>
+template <bool NT>
+__device__ __forceinline__ void st(cplx* p, cplx v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+  } else {
+    *p = v;
+  }
+}
+
+template <int NC, bool NT, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
   constexpr int E = NC * NC;
   const int e = threadIdx.x % E;
@@ -111,8 +122,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
       cplx xv[5];
 #pragma unroll
       for (int d = 0; d < 4; d++)
-        xv[d] = ((hop_mask >> d) & 1u) ? x[nb[d] * NC + c] : cmake(0.0, 0.0);
+        xv[d] = ((hop_mask >> d) & 1u) ? x[((a.ablate & 1) ? site : nb[d]) * NC + c] : cmake(0.0, 0.0);
       xv[4] = need_own ? x[site * NC + c] : cmake(0.0, 0.0);
+      if (a.ablate & 4) { xv[0] = xv[1] = xv[2] = xv[3] = xv[4] = cmake(1.0 + c, 0.5); }
 
       cplx acc = cmake(0.0, 0.0);
       cmac(acc, m[4], xv[4]);                       // clover first, as the reference does
@@ -123,9 +135,139 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
       if (NC >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
       if (NC >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
 
+      if ((a.ablate & 2) && acc.x != 1.2345e300) continue;
       if (c == 0) {
         if (!do_zero) acc = cadd(out[site * NC + r], acc);
-        out[site * NC + r] = acc;
+        st<NTS>(out + site * NC + r, acc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel A2 (nc = 1, 2, 4; both parities active): one lane group owns the EVEN and the ODD site
+// of half-row column j on ROWS consecutive rows.  The two sites (y,j) of opposite parity are
+// mutual x-neighbours (x = 2j and 2j+1, in an order set by y&1) and the rows share their
+// y-neighbours, so the right-hand side is loaded into registers once for all 2*ROWS outputs:
+// 2(ROWS+2) column values + 2 ROWS side values instead of 10 ROWS.  More importantly each
+// wavefront now streams 2*ROWS*5 matrix elements per lane (ROWS=2: 32 KiB of loads in flight per
+// wave), which takes the launch out of the "a million 6-KiB waves" regime where wave dispatch,
+// not HBM, sets the pace (tools/membw2.hip: 5.3 TB/s at 1M blocks vs 6.4-6.7 TB/s at 64K).
+// ------------------------------------------------------------------------------------------
+template <int NC, int ROWS, bool NT, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
+  constexpr int E = NC * NC;
+  const int e = threadIdx.x % E;
+  const int r = e / NC, c = e % NC;
+  const int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
+  if (j >= a.hr) return;
+  const int ngroups = a.Ly / ROWS;
+
+  bool do_clover[2], do_shift[2], do_zero[2];
+  unsigned hop_mask[2];
+  cplx sh[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    do_clover[p] = a.clover && ((a.pieces >> p) & 1u);
+    hop_mask[p] = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
+    do_shift[p] = (a.pieces >> (10 + p)) & 1u;
+    do_zero[p] = (a.pieces >> (12 + p)) & 1u;
+    sh[p] = cmake(0.0, 0.0);
+    if (do_shift[p] && r == c) {
+      const double sg = p ? -1.0 : 1.0;
+      const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+      sh[p] = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
+                    a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+    }
+  }
+  const bool any_hop = (hop_mask[0] | hop_mask[1]) != 0u;
+  int jl = j - 1; if (jl < 0) jl = a.hr - 1;
+  int jr = j + 1; if (jr == a.hr) jr = 0;
+
+  for (int grp = blockIdx.y; grp < ngroups; grp += gridDim.y) {
+    const int y0 = grp * ROWS;
+
+    // ---- stencil matrices: 2*ROWS*5 coalesced 16-byte elements per lane
+    cplx m[ROWS][2][5];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; rr++)
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const long site = (long)p * a.half_vol + (long)(y0 + rr) * a.hr + j;
+        m[rr][p][4] = do_clover[p] ? ld<NT>(a.clover + site * E + e) : cmake(0.0, 0.0);
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+          m[rr][p][d] = ((hop_mask[p] >> d) & 1u) ? ld<NT>(a.hopping + (long)d * a.size_cm + site * E + e) : cmake(0.0, 0.0);
+      }
+
+    for (int k = 0; k < a.nrhs; k++) {
+      const cplx* x = a.rhs + (long)k * a.vec_stride;
+      cplx* out = a.lhs + (long)k * a.vec_stride;
+      const cplx* xe = x;                       // even half
+      const cplx* xo = x + a.half_vol * NC;     // odd half
+
+      // ---- right-hand side: rows y0-1 .. y0+ROWS at column j, both parities
+      cplx Ec[ROWS + 2], Oc[ROWS + 2];
+#pragma unroll
+      for (int t = 0; t < ROWS + 2; t++) {
+        int yy = y0 - 1 + t;
+        if (yy < 0) yy = a.Ly - 1;
+        if (yy >= a.Ly) yy -= a.Ly;
+        const bool edge = (t == 0 || t == ROWS + 1);
+        if (!edge || any_hop) {
+          Ec[t] = xe[((long)yy * a.hr + j) * NC + c];
+          Oc[t] = xo[((long)yy * a.hr + j) * NC + c];
+        } else {
+          Ec[t] = Oc[t] = cmake(0.0, 0.0);
+        }
+      }
+      // ---- and the one x-neighbour per row that is not the partner site
+      cplx Es[ROWS], Os[ROWS];
+#pragma unroll
+      for (int rr = 0; rr < ROWS; rr++) {
+        const int y = y0 + rr;
+        const int se = y & 1;                    // even site: x = 2j + se ; odd site: x = 2j + 1 - se
+        if (any_hop) {
+          Os[rr] = xo[((long)y * a.hr + (se ? jr : jl)) * NC + c];
+          Es[rr] = xe[((long)y * a.hr + (se ? jl : jr)) * NC + c];
+        } else {
+          Os[rr] = Es[rr] = cmake(0.0, 0.0);
+        }
+      }
+
+#pragma unroll
+      for (int rr = 0; rr < ROWS; rr++) {
+        const int y = y0 + rr;
+        const int se = y & 1;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          // neighbours of the parity-p site (y, j); s = (y + p) & 1
+          const int s = p ? (1 - se) : se;
+          const cplx own = p ? Oc[rr + 1] : Ec[rr + 1];
+          const cplx partner = p ? Ec[rr + 1] : Oc[rr + 1];     // opposite parity, same (y, j)
+          const cplx side = p ? Es[rr] : Os[rr];                // opposite parity, (y, j + (s ? +1 : -1))
+          cplx xv[4];
+          xv[0] = s ? side : partner;                           // +x: (y, j + s)
+          xv[2] = s ? partner : side;                           // -x: (y, j + s - 1)
+          xv[1] = p ? Ec[rr + 2] : Oc[rr + 2];                  // +y
+          xv[3] = p ? Ec[rr] : Oc[rr];                          // -y
+          // values this parity does not ask for may be uninitialised memory: never let them into the sum
+          const cplx zero = cmake(0.0, 0.0);
+          const cplx own_u = (do_clover[p] || do_shift[p]) ? own : zero;
+          cplx acc = zero;
+          cmac(acc, m[rr][p][4], own_u);
+#pragma unroll
+          for (int d = 0; d < 4; d++) cmac(acc, m[rr][p][d], ((hop_mask[p] >> d) & 1u) ? xv[d] : zero);
+          cmac(acc, sh[p], own_u);
+          if (NC >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
+          if (NC >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
+          const bool touch = do_clover[p] || hop_mask[p] || do_shift[p] || do_zero[p];
+          if (c == 0 && touch) {
+            const long o = ((long)p * a.half_vol + (long)y * a.hr + j) * NC + r;
+            if (!do_zero[p]) acc = cadd(out[o], acc);
+            st<NTS>(out + o, acc);
+          }
+        }
       }
     }
   }
@@ -274,7 +416,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
   }
 }
 
-static int g_stencil_nt = 0;   // tuning knob: non-temporal matrix loads in kernel A
+static int g_stencil_nt = 3;     // tuning knob: bit0 non-temporal matrix loads, bit1 non-temporal stores (kernel A)
+static int g_stencil_ablate = 0;
+static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
+static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 
 static GenLayout make_gen_layout(int nc, int hr) {
   GenLayout L;
@@ -301,6 +446,9 @@ using namespace qmg;
 extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!key) return QMG_ERR_INVALID;
   if (!strcmp(key, "stencil_nt")) { g_stencil_nt = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 
@@ -323,6 +471,7 @@ extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const voi
   a.pieces = pieces;
   a.nrhs = nrhs;
   a.vec_stride = (long)vec_stride;
+  a.ablate = g_stencil_ablate;
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
 
   // which parity halves have any work
@@ -333,17 +482,48 @@ extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const voi
   a.par_first = ev ? 0 : 1;
   a.par_count = (ev && od) ? 2 : 1;
   a.nrows = d->Ly * a.par_count;
-  const unsigned gy = a.nrows > 65535 ? 65535u : (unsigned)a.nrows;
+  unsigned gy = a.nrows > 65535 ? 65535u : (unsigned)a.nrows;
+  if (g_stencil_rows > 0 && gy > (unsigned)g_stencil_rows) gy = (unsigned)g_stencil_rows;
   hipStream_t st = as_stream(stream);
+
+  if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && g_stencil_pair > 0 && lhs != rhs) {
+    const int E = nc * nc;
+    const int rows = (g_stencil_pair >= 4 && d->Ly % 4 == 0) ? 4 : (g_stencil_pair >= 2 && d->Ly % 2 == 0) ? 2 : 1;
+    const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
+    unsigned gyp = (unsigned)(d->Ly / rows);
+    if (gyp > 65535u) gyp = 65535u;
+    if (g_stencil_rows > 0 && gyp > (unsigned)g_stencil_rows) gyp = (unsigned)g_stencil_rows;
+    dim3 grid(gx, gyp), block(BLOCK);
+#define QMG_PAIR_LAUNCH(NC, ROWS)                                                             \
+    switch (g_stencil_nt & 3) {                                                               \
+      case 0: k_stencil_pair<NC, ROWS, false, false><<<grid, block, 0, st>>>(a); break;       \
+      case 1: k_stencil_pair<NC, ROWS, true, false><<<grid, block, 0, st>>>(a); break;        \
+      case 2: k_stencil_pair<NC, ROWS, false, true><<<grid, block, 0, st>>>(a); break;        \
+      default: k_stencil_pair<NC, ROWS, true, true><<<grid, block, 0, st>>>(a); break;        \
+    }
+    if (nc == 1) { if (rows == 4) { QMG_PAIR_LAUNCH(1, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(1, 2) } else { QMG_PAIR_LAUNCH(1, 1) } }
+    if (nc == 2) { if (rows == 4) { QMG_PAIR_LAUNCH(2, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(2, 2) } else { QMG_PAIR_LAUNCH(2, 1) } }
+    if (nc == 4) { if (rows >= 2) { QMG_PAIR_LAUNCH(4, 2) } else { QMG_PAIR_LAUNCH(4, 1) } }
+#undef QMG_PAIR_LAUNCH
+    QMG_LAUNCH_CHECK();
+    return QMG_SUCCESS;
+  }
 
   if (nc == 1 || nc == 2 || nc == 4) {
     const int E = nc * nc;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
     dim3 grid(gx, gy), block(BLOCK);
-    const bool nt = g_stencil_nt != 0;
-    if (nc == 1) { if (nt) k_stencil_elem<1, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<1, false><<<grid, block, 0, st>>>(a); }
-    if (nc == 2) { if (nt) k_stencil_elem<2, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<2, false><<<grid, block, 0, st>>>(a); }
-    if (nc == 4) { if (nt) k_stencil_elem<4, true><<<grid, block, 0, st>>>(a); else k_stencil_elem<4, false><<<grid, block, 0, st>>>(a); }
+#define QMG_ELEM_LAUNCH(NC)                                                                   \
+    switch (g_stencil_nt & 3) {                                                               \
+      case 0: k_stencil_elem<NC, false, false><<<grid, block, 0, st>>>(a); break;             \
+      case 1: k_stencil_elem<NC, true, false><<<grid, block, 0, st>>>(a); break;              \
+      case 2: k_stencil_elem<NC, false, true><<<grid, block, 0, st>>>(a); break;              \
+      default: k_stencil_elem<NC, true, true><<<grid, block, 0, st>>>(a); break;              \
+    }
+    if (nc == 1) { QMG_ELEM_LAUNCH(1) }
+    if (nc == 2) { QMG_ELEM_LAUNCH(2) }
+    if (nc == 4) { QMG_ELEM_LAUNCH(4) }
+#undef QMG_ELEM_LAUNCH
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }

@@ -1,0 +1,55 @@
+"""Turn gpurun_out/prof_{stats,fetch,write} (rocprofv3 CSVs) into the committed summary under profiles/.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction
+(MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request for wide coalesced
+16 B/lane streaming reads, i.e. exactly half the bytes -> doubled here; WRITE_SIZE is exact for
+16 B/lane streaming stores.
+"""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+kernel_key = sys.argv[2] if len(sys.argv) > 2 else "k_stencil_pair<2, 2"
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+stats = sorted(glob.glob(os.path.join(G, "prof_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1]
+shutil.copy(stats, os.path.join(P, "%s_kernel_stats.csv" % tag))
+rows = list(csv.DictReader(open(stats)))
+def pmc(name):
+    f = sorted(glob.glob(os.path.join(G, "prof_%s" % name, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1]
+    rs = [r for r in csv.DictReader(open(f)) if kernel_key in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rs]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rs]
+    return sum(vals) / len(vals), min(vals), max(vals), len(vals), sum(durs) / len(durs)
+fk, fmin, fmax, fn, fdur = pmc("fetch")
+wk, wmin, wmax, wn, wdur = pmc("write")
+krow = [r for r in rows if kernel_key in r["Name"]][0]
+avg_ns = float(krow["AverageNs"])
+sites = L * L
+alg = 384 * sites
+read_bytes = 2.0 * fk * 1024.0
+write_bytes = wk * 1024.0
+traffic = read_bytes + write_bytes
+out = {"tag": tag, "kernel": krow["Name"], "workload": "Wilson apply %dx%d nc=2 fp64" % (L, L), "calls": int(krow["Calls"]),
+       "avg_launch_ns": avg_ns, "min_ns": float(krow["MinNs"]), "max_ns": float(krow["MaxNs"]),
+       "algorithmic_bytes_per_launch": alg, "achieved_GBps_algorithmic": alg / avg_ns,
+       "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
+       "hbm_read_bytes_per_launch_corrected": read_bytes, "hbm_write_bytes_per_launch": write_bytes,
+       "hbm_traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg,
+       "pmc_launches": [fn, wn], "pmc_avg_launch_us": [fdur, wdur],
+       "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request on 16 B/lane streams), WRITE_SIZE exact; separate --pmc passes"}
+json.dump(out, open(os.path.join(P, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
+    f.write("# %s -- rocprofv3 summary, %s\n\n" % (tag, out["workload"]))
+    f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also`\n")
+    f.write("(PMC: same command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes, --steps 10.)\n\n")
+    f.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---:|---:|---:|---:|---:|\n")
+    for r in rows:
+        f.write("| `%s` | %s | %.0f | %s | %s | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
+    f.write("\nDominant kernel `%s`:\n\n" % kernel_key)
+    f.write("* average launch %.1f us -> %.0f GB/s of ALGORITHMIC bytes (384 B/site x %d sites = %.3f GB) = %.1f %% of 8 TB/s\n" % (avg_ns / 1e3, alg / avg_ns, sites, alg / 1e9, alg / avg_ns / 80.0))
+    f.write("* FETCH_SIZE %.0f KiB/launch (min %.0f max %.0f, %d launches) -> x2 gfx950 correction = %.3f GB read\n" % (fk, fmin, fmax, fn, read_bytes / 1e9))
+    f.write("* WRITE_SIZE %.0f KiB/launch -> %.3f GB written (exact: 32 B/site)\n" % (wk, write_bytes / 1e9))
+    f.write("* HBM traffic %.3f GB/launch = %.4f x algorithmic: no wasted re-reads (rhs read once; neighbours served by L2)\n" % (traffic / 1e9, traffic / alg))
+print(json.dumps(out, indent=1))
