@@ -43,12 +43,14 @@ typedef enum {
   QMG_ERR_NO_DEVICE = 4
 } qmg_status;
 
-/* cshift directions / parities: values identical to cshift/cshift_2d.h:13-36 */
-enum { QMG_CSHIFT_FROM_0 = 1, QMG_CSHIFT_FROM_XP1 = 2, QMG_CSHIFT_FROM_YP1 = 3,
-       QMG_CSHIFT_FROM_XM1 = 4, QMG_CSHIFT_FROM_YM1 = 5 };
-enum { QMG_EO_FROM_EVEN = 1, QMG_EO_FROM_ODD = 2, QMG_EO_FROM_EVENODD = 3 };
-/* hopping direction index: stencil/stencil_2d.h:25-40 */
-enum { QMG_DIR_INDEX_XP1 = 0, QMG_DIR_INDEX_YP1 = 1, QMG_DIR_INDEX_XM1 = 2, QMG_DIR_INDEX_YM1 = 3 };
+/* cshift directions / parities: names and values identical to cshift/cshift_2d.h:13-36 */
+typedef enum {
+  QMG_CSHIFT_FROM_0 = 1, QMG_CSHIFT_FROM_XP1 = 2, QMG_CSHIFT_FROM_YP1 = 3, QMG_CSHIFT_FROM_XM1 = 4, QMG_CSHIFT_FROM_YM1 = 5,
+  QMG_CSHIFT_FROM_XP2 = 6, QMG_CSHIFT_FROM_YP2 = 7, QMG_CSHIFT_FROM_XM2 = 8, QMG_CSHIFT_FROM_YM2 = 9,
+  QMG_CSHIFT_FROM_XP1YP1 = 10, QMG_CSHIFT_FROM_XM1YP1 = 11, QMG_CSHIFT_FROM_XM1YM1 = 12, QMG_CSHIFT_FROM_XP1YM1 = 13
+} qmg_cshift_dir;   /* only the distance-1 shifts (1..5) are implemented, as in the reference (:120-129) */
+typedef enum { QMG_EO_FROM_EVEN = 1, QMG_EO_FROM_ODD = 2, QMG_EO_FROM_EVENODD = 3 } qmg_eo;
+/* hopping direction index mu = 0..3 is {+x,+y,-x,-y} (stencil/stencil_2d.h:25-40) */
 
 /* Which pieces of  lhs (+)= M rhs  one fused launch applies.  Each reference method is one mask:
  *   apply_M            (stencil_2d.h:912-936)  QMG_P_ALL

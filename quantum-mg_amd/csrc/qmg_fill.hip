@@ -301,7 +301,7 @@ int qmg_build_dagger(void* dclover, void* dhopping, const void* clover, const vo
     QMG_LAUNCH_CHECK();
   }
   if (hopping && dhopping) {
-    const int src_dir[4] = {QMG_DIR_INDEX_XM1, QMG_DIR_INDEX_YM1, QMG_DIR_INDEX_XP1, QMG_DIR_INDEX_YP1};
+    const int src_dir[4] = {2, 3, 0, 1};   // -x, -y, +x, +y
     const int cdir[4] = {QMG_CSHIFT_FROM_XP1, QMG_CSHIFT_FROM_YP1, QMG_CSHIFT_FROM_XM1, QMG_CSHIFT_FROM_YM1};
     for (int dir = 0; dir < 4; dir++) {
       k_conjtrans<<<grid_1d((size_t)cm), BLOCK, 0, st>>>((cplx*)dhopping + dir * cm, (const cplx*)hopping + src_dir[dir] * cm,

@@ -1,0 +1,365 @@
+// krylov.hpp -- the Krylov drivers the K-cycle calls, on device-resident vectors.
+//
+// The reference takes these from quantum-linalg (`inverters/generic_*.h`, absent; only the call sites
+// are known: stateful_multigrid.h:851-990,1037-1046, tests/n13_wilson_kcycle/wilson_kcycle.cpp:459-466,
+// tests/n02_free_laplace_test/free_laplace.cpp:118).  Names, argument order and the inversion_info /
+// inversion_verbose_struct conventions follow those call sites; the algorithms are the textbook ones
+// (PARITY UNPINNED: there is no stored output of the reference's solvers anywhere).
+//   * tolerance is relative:  stop when sqrt(resSq) < tol * ||b||
+//   * resSq is the (recursive) residual norm squared at exit; iter counts iterations; ops_count counts
+//     operator applications (used by DslashTrackerMG, stateful_multigrid.h:854-865)
+// All vectors are device pointers; every reduction is a two-stage device reduction whose result comes back
+// to the host because the control flow depends on it.  GCR-type orthogonalisation uses one fused
+// multi-dot pass (qmg_multidot) instead of k separate dot kernels.
+#ifndef QMG_KRYLOV_HPP
+#define QMG_KRYLOV_HPP
+
+#include <cmath>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "qmg_device.hpp"
+
+namespace qmg {
+
+// Scratch vectors for one solve.  Returned to a per-length free list on scope exit instead of
+// hipFree (which synchronises the device): the smoothers run thousands of times per solve.
+struct VecPool {
+  std::vector<complex<double>*> v;
+  size_t n;
+  static std::map<size_t, std::vector<complex<double>*>>& cache() { static std::map<size_t, std::vector<complex<double>*>> c; return c; }
+  explicit VecPool(size_t n_) : n(n_) {}
+  complex<double>* get() {
+    std::vector<complex<double>*>& fl = cache()[n];
+    complex<double>* p;
+    if (!fl.empty()) { p = fl.back(); fl.pop_back(); } else { p = allocate_vector<complex<double>>(n); }
+    v.push_back(p);
+    return p;
+  }
+  ~VecPool() { std::vector<complex<double>*>& fl = cache()[n]; for (auto p : v) fl.push_back(p); }
+  static void release_all() { for (auto& kv : cache()) for (auto& p : kv.second) deallocate_vector(&p); cache().clear(); }
+};
+
+inline void report(inversion_verbose_struct* verb, const char* name, int iter, double rel, bool summary_only = false) {
+  if (!verb) return;
+  if (verb->verbosity == VERB_DETAIL && !summary_only)
+    std::cout << verb->verb_prefix << name << " Iter " << iter << " RelTol " << rel << "\n";
+}
+inline void summary(inversion_verbose_struct* verb, const char* name, bool ok_, int iter, double rel) {
+  if (!verb || verb->verbosity == VERB_NONE) return;
+  std::cout << verb->verb_prefix << name << (ok_ ? " Success " : " Fail ") << "Iter " << iter << " RelTol " << rel << "\n";
+}
+
+inline std::vector<complex<double>> multidot(const std::vector<complex<double>*>& xs, int k, const complex<double>* y, size_t n) {
+  std::vector<complex<double>> out(k);
+  int done = 0;
+  while (done < k) {   // the ABI takes up to 64 vectors per call
+    const int kk = (k - done > 64) ? 64 : k - done;
+    std::vector<const void*> ptrs(kk);
+    for (int i = 0; i < kk; i++) ptrs[i] = xs[done + i];
+    std::vector<double> r(2 * kk);
+    ok(qmg_multidot(ptrs.data(), kk, y, n, nullptr, r.data(), current_stream()), "qmg_multidot");
+    for (int i = 0; i < kk; i++) out[done + i] = complex<double>(r[2 * i], r[2 * i + 1]);
+    done += kk;
+  }
+  return out;
+}
+
+}  // namespace qmg
+
+// ---------------------------------------------------------------------------------------------
+// MinRes / MR with relaxation omega (minv_vector_minres(x, b, n, iters, tol, omega, op, opdata)).
+//   r = b - A x ; repeat: p = A r ; alpha = <p,r>/<p,p> ; x += omega alpha r ; r -= omega alpha p
+// ---------------------------------------------------------------------------------------------
+inline inversion_info minv_vector_minres(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, double omega,
+                                         matrix_op_cplx matrix_vector, void* extra_info, inversion_verbose_struct* verb = 0) {
+  inversion_info invif;
+  invif.name = "MinRes (relaxation parameter " + std::to_string(omega) + ")";
+  qmg::VecPool pool(size);
+  complex<double>* r = pool.get();
+  complex<double>* p = pool.get();
+  const double bsq = norm2sq(phi0, size);
+  const double bnorm = std::sqrt(bsq);
+  int ops = 0;
+  // r = b - A x
+  matrix_vector(p, phi, extra_info); ops++;
+  caxpbyz(1.0, phi0, -1.0, p, r, size);
+  double rsq = norm2sq(r, size);
+  int k = 0;
+  bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
+  while (!conv && k < max_iter) {
+    matrix_vector(p, r, extra_info); ops++;
+    const complex<double> pr = dot(p, r, size);
+    const double pp = norm2sq(p, size);
+    if (pp == 0.0) break;
+    const complex<double> alpha = omega * pr / pp;
+    caxpy(alpha, r, phi, size);
+    caxpy(-alpha, p, r, size);
+    rsq = norm2sq(r, size);
+    k++;
+    qmg::report(verb, "MinRes", k, std::sqrt(rsq) / bnorm);
+    if (std::sqrt(rsq) < eps * bnorm) conv = true;
+  }
+  invif.success = conv;
+  invif.iter = k;
+  invif.resSq = rsq;
+  invif.ops_count = ops;
+  qmg::summary(verb, "MinRes", conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
+  return invif;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CG (Hermitian positive definite op): minv_vector_cg(x, b, n, max_iter, tol, op, opdata, verb)
+// ---------------------------------------------------------------------------------------------
+inline inversion_info minv_vector_cg(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, matrix_op_cplx matrix_vector,
+                                     void* extra_info, inversion_verbose_struct* verb = 0) {
+  inversion_info invif;
+  invif.name = "CG";
+  qmg::VecPool pool(size);
+  complex<double>*r = pool.get(), *p = pool.get(), *Ap = pool.get();
+  const double bnorm = std::sqrt(norm2sq(phi0, size));
+  int ops = 0;
+  matrix_vector(Ap, phi, extra_info); ops++;
+  caxpbyz(1.0, phi0, -1.0, Ap, r, size);
+  copy_vector(p, r, size);
+  double rsq = norm2sq(r, size);
+  int k = 0;
+  bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
+  while (!conv && k < max_iter) {
+    matrix_vector(Ap, p, extra_info); ops++;
+    const double pAp = dot(p, Ap, size).real();
+    if (pAp == 0.0) break;
+    const double alpha = rsq / pAp;
+    caxpy(alpha, p, phi, size);
+    caxpy(-alpha, Ap, r, size);
+    const double rsq_new = norm2sq(r, size);
+    k++;
+    qmg::report(verb, "CG", k, std::sqrt(rsq_new) / bnorm);
+    if (std::sqrt(rsq_new) < eps * bnorm) { rsq = rsq_new; conv = true; break; }
+    const double beta = rsq_new / rsq;
+    rsq = rsq_new;
+    cxpay(r, beta, p, size);   // p = r + beta p
+  }
+  invif.success = conv; invif.iter = k; invif.resSq = rsq; invif.ops_count = ops;
+  qmg::summary(verb, "CG", conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
+  return invif;
+}
+
+inline inversion_info minv_vector_cg_restart(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, int restart_freq,
+                                             matrix_op_cplx matrix_vector, void* extra_info, inversion_verbose_struct* verb = 0) {
+  inversion_info total;
+  total.name = "Restarted CG(" + std::to_string(restart_freq) + ")";
+  const double bnorm = std::sqrt(norm2sq(phi0, size));
+  while (total.iter < max_iter) {
+    const int chunk = (max_iter - total.iter < restart_freq) ? max_iter - total.iter : restart_freq;
+    inversion_info one = minv_vector_cg(phi, phi0, size, chunk, eps, matrix_vector, extra_info, 0);
+    total.iter += one.iter; total.ops_count += one.ops_count; total.resSq = one.resSq; total.success = one.success;
+    if (one.success || one.iter == 0) break;
+  }
+  qmg::summary(verb, "CG-restart", total.success, total.iter, bnorm > 0 ? std::sqrt(total.resSq) / bnorm : 0.0);
+  return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flexible (variable-preconditioned) GCR with optional restarts -- the K-cycle's Krylov wrapper.
+//   r = b - A x
+//   loop:  z_k = M^-1 r (preconditioner; identity when precond == 0)
+//          w_k = A z_k ; orthogonalise w_k against w_0..w_{k-1} (and carry z_k along)
+//          alpha = <w_k, r>/<w_k,w_k> ; x += alpha z_k ; r -= alpha w_k
+//   restart_freq > 0: the basis is dropped every restart_freq directions.
+// ---------------------------------------------------------------------------------------------
+inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, int restart_freq,
+                                   matrix_op_cplx matrix_vector, void* extra_info, precond_op_cplx precond, void* precond_info,
+                                   inversion_verbose_struct* verb, const char* name) {
+  inversion_info invif;
+  invif.name = name;
+  const int basis_max = (restart_freq > 0) ? restart_freq : max_iter;
+  qmg::VecPool pool(size);
+  complex<double>* r = pool.get();
+  complex<double>* tmp = pool.get();
+  std::vector<complex<double>*> Z, W;     // search directions and their images, allocated on demand
+  std::vector<double> Wnorm2;
+  const double bnorm = std::sqrt(norm2sq(phi0, size));
+  int ops = 0;
+  matrix_vector(tmp, phi, extra_info); ops++;
+  caxpbyz(1.0, phi0, -1.0, tmp, r, size);
+  double rsq = norm2sq(r, size);
+  bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
+  int k = 0, kb = 0;   // total iterations, index within the current basis
+  inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
+  if (verb) { pverb.precond_verbosity = verb->precond_verbosity; pverb.precond_verb_prefix = verb->precond_verb_prefix; }
+  while (!conv && k < max_iter) {
+    if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(0.0); }
+    complex<double>* z = Z[kb];
+    complex<double>* w = W[kb];
+    if (precond) { zero_vector(z, size); precond(z, r, size, precond_info, &pverb); }
+    else copy_vector(z, r, size);
+    matrix_vector(w, z, extra_info); ops++;
+    if (kb > 0) {   // modified-in-one-pass Gram-Schmidt against the current basis
+      std::vector<complex<double>> c = qmg::multidot(W, kb, w, size);
+      for (int i = 0; i < kb; i++) {
+        const complex<double> beta = c[i] / Wnorm2[i];
+        caxpy(-beta, W[i], w, size);
+        caxpy(-beta, Z[i], z, size);
+      }
+    }
+    const double ww = norm2sq(w, size);
+    if (ww == 0.0) break;
+    Wnorm2[kb] = ww;
+    const complex<double> alpha = dot(w, r, size) / ww;
+    caxpy(alpha, z, phi, size);
+    caxpy(-alpha, w, r, size);
+    rsq = norm2sq(r, size);
+    k++; kb++;
+    qmg::report(verb, name, k, std::sqrt(rsq) / bnorm);
+    if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
+    if (kb == basis_max) {   // restart: recompute the true residual, drop the basis
+      matrix_vector(tmp, phi, extra_info); ops++;
+      caxpbyz(1.0, phi0, -1.0, tmp, r, size);
+      rsq = norm2sq(r, size);
+      kb = 0;
+      if (verb && verb->verbosity >= VERB_RESTART_DETAIL) std::cout << verb->verb_prefix << name << " restart at iter " << k << " RelTol " << std::sqrt(rsq) / bnorm << "\n";
+      if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
+    }
+  }
+  invif.success = conv; invif.iter = k; invif.resSq = rsq; invif.ops_count = ops;
+  qmg::summary(verb, name, conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
+  return invif;
+}
+
+inline inversion_info minv_vector_gcr(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, matrix_op_cplx op, void* opd,
+                                      inversion_verbose_struct* verb = 0) {
+  return qmg_gcr_core(phi, phi0, size, max_iter, eps, -1, op, opd, 0, 0, verb, "GCR");
+}
+inline inversion_info minv_vector_gcr_restart(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, int restart_freq,
+                                              matrix_op_cplx op, void* opd, inversion_verbose_struct* verb = 0) {
+  return qmg_gcr_core(phi, phi0, size, max_iter, eps, restart_freq, op, opd, 0, 0, verb, "GCR-restart");
+}
+inline inversion_info minv_vector_gcr_var_precond(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, matrix_op_cplx op,
+                                                  void* opd, precond_op_cplx precond, void* precd, inversion_verbose_struct* verb = 0) {
+  return qmg_gcr_core(phi, phi0, size, max_iter, eps, -1, op, opd, precond, precd, verb, "VPGCR");
+}
+inline inversion_info minv_vector_gcr_var_precond_restart(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps,
+                                                          int restart_freq, matrix_op_cplx op, void* opd, precond_op_cplx precond, void* precd,
+                                                          inversion_verbose_struct* verb = 0) {
+  return qmg_gcr_core(phi, phi0, size, max_iter, eps, restart_freq, op, opd, precond, precd, verb, "VPGCR-restart");
+}
+
+// ---------------------------------------------------------------------------------------------
+// BiCGStab(L) (Sleijpen & Fokkema 1993): minv_vector_bicgstab_l(x, b, n, max_iter, tol, L, op, opdata, verb)
+// -- the null-vector relaxation of tests/n13_wilson_kcycle/wilson_kcycle.cpp:359.  `iter` counts BiCG steps.
+// ---------------------------------------------------------------------------------------------
+inline inversion_info minv_vector_bicgstab_l(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, int L,
+                                             matrix_op_cplx matrix_vector, void* extra_info, inversion_verbose_struct* verb = 0) {
+  inversion_info invif;
+  invif.name = "BiCGStab-" + std::to_string(L);
+  qmg::VecPool pool(size);
+  std::vector<complex<double>*> r(L + 1), u(L + 1);
+  for (int i = 0; i <= L; i++) { r[i] = pool.get(); u[i] = pool.get(); }
+  complex<double>* rt = pool.get();
+  const double bnorm = std::sqrt(norm2sq(phi0, size));
+  int ops = 0;
+  matrix_vector(u[0], phi, extra_info); ops++;
+  caxpbyz(1.0, phi0, -1.0, u[0], r[0], size);
+  copy_vector(rt, r[0], size);
+  zero_vector(u[0], size);
+  complex<double> rho0 = 1.0, alpha = 0.0, omega = 1.0;
+  double rsq = norm2sq(r[0], size);
+  bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
+  int k = 0;
+  std::vector<complex<double>> tau((L + 1) * (L + 1)), gamma(L + 1), gammap(L + 1), gammapp(L + 1);
+  std::vector<double> sigma(L + 1);
+  bool breakdown = false;
+  while (!conv && k < max_iter && !breakdown) {
+    rho0 = -omega * rho0;
+    for (int j = 0; j < L && !breakdown; j++) {   // BiCG part
+      const complex<double> rho1 = dot(rt, r[j], size);
+      if (rho0 == 0.0) { breakdown = true; break; }
+      const complex<double> beta = alpha * rho1 / rho0;
+      rho0 = rho1;
+      for (int i = 0; i <= j; i++) cxpay(r[i], -beta, u[i], size);   // u_i = r_i - beta u_i
+      matrix_vector(u[j + 1], u[j], extra_info); ops++;
+      const complex<double> gam = dot(rt, u[j + 1], size);
+      if (gam == 0.0) { breakdown = true; break; }
+      alpha = rho0 / gam;
+      for (int i = 0; i <= j; i++) caxpy(-alpha, u[i + 1], r[i], size);
+      matrix_vector(r[j + 1], r[j], extra_info); ops++;
+      caxpy(alpha, u[0], phi, size);
+      k++;
+    }
+    if (breakdown) break;
+    for (int j = 1; j <= L; j++) {   // MR part: modified Gram-Schmidt on r_1..r_L
+      for (int i = 1; i < j; i++) {
+        tau[i * (L + 1) + j] = dot(r[i], r[j], size) / sigma[i];
+        caxpy(-tau[i * (L + 1) + j], r[i], r[j], size);
+      }
+      sigma[j] = norm2sq(r[j], size);
+      if (sigma[j] == 0.0) { breakdown = true; break; }
+      gammap[j] = dot(r[j], r[0], size) / sigma[j];
+    }
+    if (breakdown) break;
+    gamma[L] = gammap[L];
+    omega = gamma[L];
+    for (int j = L - 1; j >= 1; j--) {
+      gamma[j] = gammap[j];
+      for (int i = j + 1; i <= L; i++) gamma[j] -= tau[j * (L + 1) + i] * gamma[i];
+    }
+    for (int j = 1; j < L; j++) {
+      gammapp[j] = gamma[j + 1];
+      for (int i = j + 1; i < L; i++) gammapp[j] += tau[j * (L + 1) + i] * gamma[i + 1];
+    }
+    caxpy(gamma[1], r[0], phi, size);
+    caxpy(-gammap[L], r[L], r[0], size);
+    caxpy(-gamma[L], u[L], u[0], size);
+    for (int j = 1; j < L; j++) {
+      caxpy(-gamma[j], u[j], u[0], size);
+      caxpy(gammapp[j], r[j], phi, size);
+      caxpy(-gammap[j], r[j], r[0], size);
+    }
+    rsq = norm2sq(r[0], size);
+    qmg::report(verb, "BiCGStab-L", k, std::sqrt(rsq) / bnorm);
+    if (std::sqrt(rsq) < eps * bnorm) conv = true;
+  }
+  invif.success = conv; invif.iter = k; invif.resSq = rsq; invif.ops_count = ops;
+  qmg::summary(verb, "BiCGStab-L", conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
+  return invif;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Richardson relaxation (null-vector generation, tests/n22...:289):
+//   minv_vector_richardson(x, b, n, max_iter, tol, omega, check_freq, op, opdata)
+//   x += omega (b - A x); the residual norm is only evaluated every check_freq iterations.
+// ---------------------------------------------------------------------------------------------
+inline inversion_info minv_vector_richardson(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, double omega,
+                                             int check_freq, matrix_op_cplx matrix_vector, void* extra_info, inversion_verbose_struct* verb = 0) {
+  inversion_info invif;
+  invif.name = "Richardson";
+  qmg::VecPool pool(size);
+  complex<double>*r = pool.get(), *Ax = pool.get();
+  const double bnorm = std::sqrt(norm2sq(phi0, size));
+  int ops = 0, k = 0;
+  double rsq = 0.0;
+  bool conv = false;
+  while (k < max_iter) {
+    matrix_vector(Ax, phi, extra_info); ops++;
+    caxpbyz(1.0, phi0, -1.0, Ax, r, size);
+    if (check_freq > 0 && (k % check_freq) == 0) {
+      rsq = norm2sq(r, size);
+      if (bnorm == 0.0 || std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
+    }
+    caxpy(omega, r, phi, size);
+    k++;
+  }
+  if (!conv) {
+    matrix_vector(Ax, phi, extra_info); ops++;
+    rsq = diffnorm2sq(phi0, Ax, size);
+    conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
+  }
+  invif.success = conv; invif.iter = k; invif.resSq = rsq; invif.ops_count = ops;
+  qmg::summary(verb, "Richardson", conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
+  return invif;
+}
+
+#endif

@@ -1,0 +1,684 @@
+// stencil2d.hpp -- Stencil2D on device arrays: the reference's operator class
+// (stencil/stencil_2d.h:117-2568) rebuilt over the C-ABI.  Same public data (`lat`, `clover`,
+// `hopping`, `shift`, `eo_shift`, `dof_shift`, `built_*`, the variant arrays), same method names and
+// accumulate-into-lhs semantics, same [QMG-WARNING]/[QMG-ERROR] print-and-return behaviour.
+// Every `complex<double>*` is a DEVICE pointer; each apply is ONE fused kernel launch instead of
+// the reference's cshift + cMATxpy passes.
+#ifndef QMG_STENCIL2D_HPP
+#define QMG_STENCIL2D_HPP
+
+#include <algorithm>
+#include <iostream>
+#include <string>
+
+#include "cshift2d.hpp"
+#include "lattice2d.hpp"
+#include "qmg_device.hpp"
+
+using std::cout;
+using std::string;
+
+// stencil_2d.h:25-94: identical enumerator values
+enum stencil_dir_index {
+  QMG_DIR_INDEX_0 = 0, QMG_DIR_INDEX_XP1 = 0, QMG_DIR_INDEX_YP1 = 1, QMG_DIR_INDEX_XM1 = 2, QMG_DIR_INDEX_YM1 = 3,
+  QMG_DIR_INDEX_XP2 = 0, QMG_DIR_INDEX_YP2 = 1, QMG_DIR_INDEX_XM2 = 2, QMG_DIR_INDEX_YM2 = 3,
+  QMG_DIR_INDEX_XP1YP1 = 0, QMG_DIR_INDEX_XM1YP1 = 1, QMG_DIR_INDEX_XM1YM1 = 2, QMG_DIR_INDEX_XP1YM1 = 3,
+};
+enum stencil_pieces {
+  QMG_PIECE_CLOVER = 1, QMG_PIECE_HOPPING = 2, QMG_PIECE_TWOLINK = 4, QMG_PIECE_CORNER = 8,
+  QMG_PIECE_CLOVER_HOPPING = 3, QMG_PIECE_TWOLINK_CORNER = 12, QMG_PIECE_ALL = 15,
+};
+enum chirality_state { QMG_CHIRAL_NO = 0, QMG_CHIRAL_YES = 1, QMG_CHIRAL_UNKNOWN = 2 };
+enum QMGStencilType {
+  QMG_MATVEC_ORIGINAL = 0, QMG_MATVEC_DAGGER = 1, QMG_MATVEC_RIGHT_JACOBI = 2, QMG_MATVEC_RIGHT_SCHUR = 3,
+  QMG_MATVEC_M_MDAGGER = 4, QMG_MATVEC_MDAGGER_M = 5, QMG_MATVEC_RBJ_DAGGER = 6, QMG_MATVEC_RBJ_M_MDAGGER = 7,
+  QMG_MATVEC_RBJ_MDAGGER_M = 8,
+};
+enum QMGDefaultChirality { QMG_CHIRALITY_NONE = 0, QMG_CHIRALITY_GAMMA_5 = 1, QMG_CHIRALITY_SIGMA_1 = 2 };
+enum QMGSigmaType {
+  QMG_SIGMA_NONE = 0, QMG_SIGMA_DEFAULT = 1, QMG_GAMMA_5 = 2, QMG_SIGMA_1 = 3, QMG_GAMMA_5_L_RBJ = 4, QMG_GAMMA_5_R_RBJ = 5,
+};
+
+void apply_stencil_2D_M(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_dagger_M(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_M_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_rbjacobi(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_rbjacobi_schur(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_rbj_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_rbjacobi_MMD(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+void apply_stencil_2D_M_rbjacobi_MDM(complex<double>* lhs, complex<double>* rhs, void* extra_data);
+
+struct Stencil2D {
+ protected:
+  Stencil2D(Stencil2D const&);
+  Stencil2D& operator=(Stencil2D const&);
+
+  complex<double>* priv_cmatrix;    // kept for interface parity; the fused kernels need no cshift scratch
+  complex<double>* priv_cvector;
+  complex<double>* extra_cvector;   // exposed scratch (stencil_2d.h:129,440-443)
+  complex<double>* eo_cvector;      // Schur scratch, allocated on demand (:132,1897)
+
+  complex<double> shift_backup, eo_shift_backup, dof_shift_backup;
+  bool swap_dagger, swap_rbjacobi, swap_rbj_dagger;
+
+  // ---- the one launch every apply method goes through ----
+  void launch(unsigned pieces, complex<double>* lhs, complex<double>* rhs, const complex<double>* cl, const complex<double>* ho,
+              complex<double> s, complex<double> es, complex<double> ds) {
+    qmg_stencil_desc d;
+    d.Lx = lat->get_dim_mu(0); d.Ly = lat->get_dim_mu(1); d.nc = lat->get_nc();
+    d.clover = cl; d.hopping = ho;
+    d.shift[0] = s.real(); d.shift[1] = s.imag();
+    d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
+    d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    qmg::ok(qmg_stencil_apply(&d, lhs, rhs, pieces, 1, 0, qmg::current_stream()), "qmg_stencil_apply");
+  }
+  void launch(unsigned pieces, complex<double>* lhs, complex<double>* rhs) { launch(pieces, lhs, rhs, clover, hopping, shift, eo_shift, dof_shift); }
+
+ public:
+  Lattice2D* lat;
+  complex<double>* clover;    // device, size_cm
+  complex<double>* hopping;   // device, size_hopping  (+x,+y,-x,-y)
+  complex<double>* twolink;   // allocated on request, unimplemented in the reference too (:925-933)
+  complex<double>* corner;
+  bool generated;
+  complex<double> shift, eo_shift, dof_shift;
+
+  bool built_dagger;
+  complex<double>*dagger_clover, *dagger_hopping, *dagger_twolink, *dagger_corner;
+  bool built_rbjacobi;
+  complex<double>*rbjacobi_clover, *rbjacobi_hopping, *rbjacobi_twolink, *rbjacobi_corner, *rbjacobi_cinv;
+  bool built_rbj_dagger;
+  complex<double>*rbj_dagger_clover, *rbj_dagger_hopping, *rbj_dagger_twolink, *rbj_dagger_corner, *rbj_dagger_cinv;
+
+  qmg_stencil_desc desc() const {   // for direct C-ABI users
+    qmg_stencil_desc d;
+    d.Lx = lat->get_dim_mu(0); d.Ly = lat->get_dim_mu(1); d.nc = lat->get_nc();
+    d.clover = clover; d.hopping = hopping;
+    d.shift[0] = shift.real(); d.shift[1] = shift.imag();
+    d.eo_shift[0] = eo_shift.real(); d.eo_shift[1] = eo_shift.imag();
+    d.dof_shift[0] = dof_shift.real(); d.dof_shift[1] = dof_shift.imag();
+    return d;
+  }
+
+  Stencil2D(Lattice2D* in_lat, int pieces, complex<double> in_shift = 0.0, complex<double> in_eo_shift = 0.0, complex<double> in_dof_shift = 0.0)
+      : lat(in_lat), shift(in_shift), eo_shift(in_eo_shift), dof_shift(in_dof_shift) {
+    generated = false;
+    clover = (pieces & QMG_PIECE_CLOVER) ? allocate_vector<complex<double>>(lat->get_size_cm_l()) : 0;
+    hopping = (pieces & QMG_PIECE_HOPPING) ? allocate_vector<complex<double>>(lat->get_size_hopping_l()) : 0;
+    twolink = (pieces & QMG_PIECE_TWOLINK) ? allocate_vector<complex<double>>(lat->get_size_hopping_l()) : 0;
+    corner = (pieces & QMG_PIECE_CORNER) ? allocate_vector<complex<double>>(lat->get_size_hopping_l()) : 0;
+    priv_cmatrix = 0;   // allocated lazily: only the host-visible scratch users need it
+    priv_cvector = 0;
+    extra_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
+    eo_cvector = 0;
+    built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
+    built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
+    built_rbj_dagger = false; rbj_dagger_clover = rbj_dagger_hopping = rbj_dagger_twolink = rbj_dagger_corner = rbj_dagger_cinv = 0;
+    shift_backup = shift; eo_shift_backup = eo_shift; dof_shift_backup = dof_shift;
+    swap_dagger = swap_rbjacobi = swap_rbj_dagger = false;
+  }
+
+  virtual ~Stencil2D() {
+    complex<double>** all[] = {&clover, &hopping, &twolink, &corner, &priv_cmatrix, &priv_cvector, &extra_cvector, &eo_cvector,
+                               &dagger_clover, &dagger_hopping, &dagger_twolink, &dagger_corner,
+                               &rbjacobi_clover, &rbjacobi_hopping, &rbjacobi_twolink, &rbjacobi_corner, &rbjacobi_cinv,
+                               &rbj_dagger_clover, &rbj_dagger_hopping, &rbj_dagger_twolink, &rbj_dagger_corner, &rbj_dagger_cinv};
+    for (auto p : all) if (*p != 0) deallocate_vector(p);
+    built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
+  }
+
+  void clear_stencils() {   // stencil_2d.h:339-375
+    if (clover != 0) zero_vector(clover, lat->get_size_cm_l());
+    if (hopping != 0) zero_vector(hopping, lat->get_size_hopping_l());
+    if (twolink != 0) zero_vector(twolink, lat->get_size_hopping_l());
+    if (corner != 0) zero_vector(corner, lat->get_size_hopping_l());
+    if (built_dagger) {
+      if (dagger_clover != 0) zero_vector(dagger_clover, lat->get_size_cm_l());
+      if (dagger_hopping != 0) zero_vector(dagger_hopping, lat->get_size_hopping_l());
+      built_dagger = false;
+    }
+    if (built_rbjacobi) {
+      if (rbjacobi_clover != 0) zero_vector(rbjacobi_clover, lat->get_size_cm_l());
+      if (rbjacobi_hopping != 0) zero_vector(rbjacobi_hopping, lat->get_size_hopping_l());
+      if (rbjacobi_cinv != 0) zero_vector(rbjacobi_cinv, lat->get_size_cm_l());
+      built_rbjacobi = false;
+    }
+    if (built_rbj_dagger) {
+      if (rbj_dagger_clover != 0) zero_vector(rbj_dagger_clover, lat->get_size_cm_l());
+      if (rbj_dagger_hopping != 0) zero_vector(rbj_dagger_hopping, lat->get_size_hopping_l());
+      built_rbj_dagger = false;   // the reference resets built_rbjacobi here (:371), an apparent typo; the intent is kept
+    }
+    generated = false;
+  }
+
+  void prune_stencils(int pieces) {   // :379-404
+    if ((pieces & QMG_PIECE_CLOVER) && clover != 0) deallocate_vector(&clover);
+    if ((pieces & QMG_PIECE_HOPPING) && hopping != 0) deallocate_vector(&hopping);
+    if ((pieces & QMG_PIECE_TWOLINK) && twolink != 0) deallocate_vector(&twolink);
+    if ((pieces & QMG_PIECE_CORNER) && corner != 0) deallocate_vector(&corner);
+    if (clover == 0 && hopping == 0 && twolink == 0 && corner == 0) generated = false;
+  }
+
+  void try_prune_stencils(int pieces, double tol) {   // :407-431
+    if ((pieces & QMG_PIECE_CLOVER) && clover != 0 && norminf(clover, lat->get_size_cm_l()) < tol) deallocate_vector(&clover);
+    if ((pieces & QMG_PIECE_HOPPING) && hopping != 0 && norminf(hopping, lat->get_size_hopping_l()) < tol) deallocate_vector(&hopping);
+    if ((pieces & QMG_PIECE_TWOLINK) && twolink != 0 && norminf(twolink, lat->get_size_hopping_l()) < tol) deallocate_vector(&twolink);
+    if ((pieces & QMG_PIECE_CORNER) && corner != 0 && norminf(corner, lat->get_size_hopping_l()) < tol) deallocate_vector(&corner);
+    if (clover == 0 && hopping == 0 && twolink == 0 && corner == 0) generated = false;
+  }
+
+  Lattice2D* get_lattice() { return lat; }
+  complex<double>* expose_internal_cvector() { return extra_cvector; }
+
+  // Print the full stencil at one site (:447-635); entries are fetched from the device.
+  void print_stencil_site(int x, int y, string prefix = "") {
+    const int nc = lat->get_nc();
+    if (shift != 0.0) cout << prefix << "Shift " << shift << "\n";
+    if (eo_shift != 0.0) cout << prefix << "EO-Shift " << eo_shift << "\n";
+    if (dof_shift != 0.0) cout << prefix << "DOF-Shift " << dof_shift << "\n";
+    auto block = [&](const char* title, const complex<double>* base, long index) {
+      cout << prefix << title << "\n";
+      std::vector<complex<double>> m = qmg::to_host(base + index, (size_t)nc * nc);
+      for (int i = 0; i < nc; i++) {
+        cout << prefix;
+        for (int j = 0; j < nc; j++) cout << m[i * nc + j] << " ";
+        cout << "\n";
+      }
+    };
+    if (clover != 0) block("Clover", clover, lat->cm_coord_to_index(x, y, 0, 0));
+    if (hopping != 0) {
+      const char* names[4] = {"Hopping +x", "Hopping +y", "Hopping -x", "Hopping -y"};
+      for (int mu = 0; mu < 4; mu++) block(names[mu], hopping, lat->hopping_coord_to_index(x, y, 0, 0, mu));
+    }
+  }
+
+  void update_shifts(complex<double> a, complex<double> b, complex<double> c) { shift = shift_backup = a; eo_shift = eo_shift_backup = b; dof_shift = dof_shift_backup = c; }
+  void update_shift(complex<double> a) { shift = shift_backup = a; }
+  void update_eo_shift(complex<double> a) { eo_shift = eo_shift_backup = a; }
+  void update_dof_shift(complex<double> a) { dof_shift = dof_shift_backup = a; }
+
+  // ================= apply pieces (accumulate into lhs), stencil_2d.h:666-936 =================
+  void apply_M_ee(complex<double>* lhs, complex<double>* rhs) {   // note: plain `shift` only (:676)
+    if (clover == 0) return;
+    launch(QMG_P_CLOVER_E | QMG_P_SHIFT_E, lhs, rhs, clover, 0, shift, 0.0, 0.0);
+  }
+  void apply_M_oo(complex<double>* lhs, complex<double>* rhs) {
+    if (clover == 0) return;
+    launch(QMG_P_CLOVER_O | QMG_P_SHIFT_O, lhs, rhs, clover, 0, shift, 0.0, 0.0);
+  }
+  void apply_M_clover(complex<double>* lhs, complex<double>* rhs) {
+    if (clover == 0) return;
+    launch(QMG_P_CLOVER, lhs, rhs);
+  }
+  void apply_M_eo(complex<double>* lhs, complex<double>* rhs) {
+    if (hopping == 0) { cout << "[QMG-WARNING]: Attempt to call 'apply_M_eo' without hopping term.\n"; return; }
+    launch(QMG_P_EO, lhs, rhs);
+  }
+  void apply_M_eo(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) {
+    if (hopping == 0) { cout << "[QMG-WARNING]: Attempt to call 'apply_M_eo' without hopping term.\n"; return; }
+    launch(QMG_P_EO_XP1 << (int)dir, lhs, rhs);
+  }
+  void apply_M_oe(complex<double>* lhs, complex<double>* rhs) {
+    if (hopping == 0) { cout << "[QMG-WARNING]: Attempt to call 'apply_M_oe' without hopping term.\n"; return; }
+    launch(QMG_P_OE, lhs, rhs);
+  }
+  void apply_M_oe(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) {
+    if (hopping == 0) { cout << "[QMG-WARNING]: Attempt to call 'apply_M_oe' without hopping term.\n"; return; }
+    launch(QMG_P_OE_XP1 << (int)dir, lhs, rhs);
+  }
+  void apply_M_hopping(complex<double>* lhs, complex<double>* rhs) {
+    if (hopping != 0) launch(QMG_P_HOPPING, lhs, rhs);
+  }
+  void apply_M_hopping(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) {
+    if (hopping != 0) launch((QMG_P_EO_XP1 << (int)dir) | (QMG_P_OE_XP1 << (int)dir), lhs, rhs);
+  }
+  void apply_M_shift(complex<double>* lhs, complex<double>* rhs) { launch(QMG_P_SHIFT, lhs, rhs); }
+
+  // lhs += A rhs: one fused launch (clover + eo + oe + shifts)
+  void apply_M(complex<double>* lhs, complex<double>* rhs) {
+    if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
+    if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
+    launch(QMG_P_ALL, lhs, rhs);
+  }
+  // lhs = A rhs without a separate zeroing pass (what the C wrappers do, :2571-2576)
+  void apply_M_overwrite(complex<double>* lhs, complex<double>* rhs) { launch(QMG_P_ALL | QMG_P_ZERO, lhs, rhs); }
+
+  complex<double> get_shift() { return shift; }
+  complex<double> get_shift_eo() { return eo_shift; }
+  complex<double> get_shift_dof() { return dof_shift; }
+
+  static int get_dof(int i = 0) { return -1; }
+  static chirality_state has_chirality() { return QMG_CHIRAL_UNKNOWN; }
+
+  virtual void gamma5(complex<double>* vec) { return; }
+  virtual void gamma5(complex<double>* g5_vec, complex<double>* vec) { copy_vector(g5_vec, vec, lat->get_size_cv_l()); }
+  virtual void chiral_projection(complex<double>* vector, bool is_up) = 0;
+  virtual void chiral_projection_copy(complex<double>* orig, complex<double>* dest, bool is_up) = 0;
+  virtual void chiral_projection_both(complex<double>* orig_to_up, complex<double>* down) = 0;
+  virtual void sigma1(complex<double>* vec) { return; }
+  virtual void sigma1(complex<double>* s1_vec, complex<double>* vec) { copy_vector(s1_vec, vec, lat->get_size_cv_l()); }
+  virtual QMGDefaultChirality get_default_chirality() = 0;
+
+  void apply_sigma(complex<double>* output, complex<double>* input, QMGSigmaType type = QMG_SIGMA_DEFAULT) {   // :1015-1073
+    const long cv = lat->get_size_cv_l();
+    switch (type) {
+      case QMG_SIGMA_NONE: copy_vector(output, input, cv); break;
+      case QMG_SIGMA_DEFAULT:
+        switch (get_default_chirality()) {
+          case QMG_CHIRALITY_SIGMA_1: sigma1(output, input); break;
+          case QMG_CHIRALITY_GAMMA_5: gamma5(output, input); break;
+          default: copy_vector(output, input, cv); break;
+        }
+        break;
+      case QMG_GAMMA_5: gamma5(output, input); break;
+      case QMG_SIGMA_1: sigma1(output, input); break;
+      case QMG_GAMMA_5_R_RBJ:
+        if (!built_rbjacobi) {
+          std::cout << "[QMG-ERROR]: In apply_sigma, cannot apply QMG_GAMMA_5_L_RBJ without rbjacobi stencil.\n";
+          copy_vector(output, input, cv);
+        } else {   // B gamma_5: clover + mass
+          gamma5(extra_cvector, input);
+          launch(QMG_P_CLOVER | QMG_P_SHIFT | QMG_P_ZERO, output, extra_cvector, clover, 0, shift, 0.0, 0.0);
+        }
+        break;
+      case QMG_GAMMA_5_L_RBJ:
+        if (!built_rbj_dagger) {
+          std::cout << "[QMG-ERROR]: In apply_sigma, cannot apply QMG_GAMMA_5_R_RBJ without rbjacobi stencil.\n";
+          copy_vector(output, input, cv);
+        } else {
+          gamma5(extra_cvector, input);
+          launch(QMG_P_CLOVER | QMG_P_ZERO, output, extra_cvector, rbj_dagger_cinv, 0, 0.0, 0.0, 0.0);
+        }
+        break;
+    }
+  }
+
+  // ================= dagger stencil (:1080-1446) =================
+  void build_dagger_stencil() {
+    if (built_dagger) { std::cout << "[QMG-WARNING]: Tried to call build_dagger_stencil, but it's already been called once.\n"; return; }
+    if (clover != 0) dagger_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
+    if (hopping != 0) dagger_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
+    qmg::ok(qmg_build_dagger(dagger_clover, dagger_hopping, clover, hopping, lat->get_dim_mu(0), lat->get_dim_mu(1), lat->get_nc(), qmg::current_stream()),
+            "qmg_build_dagger");
+    if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
+    if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
+    built_dagger = true;
+  }
+
+  bool perform_swap_dagger() {   // :1142-1178
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call perform_swap_dagger, but the dagger stencil has not been allocated.\n"; return false; }
+    std::swap(clover, dagger_clover); std::swap(hopping, dagger_hopping);
+    std::swap(twolink, dagger_twolink); std::swap(corner, dagger_corner);
+    if (!swap_dagger) {
+      shift = std::conj(shift); eo_shift = std::conj(eo_shift); dof_shift = std::conj(dof_shift);
+      swap_dagger = true;
+    } else {
+      shift = shift_backup; eo_shift = eo_shift_backup; dof_shift = dof_shift_backup;
+      swap_dagger = false;
+    }
+    return swap_dagger;
+  }
+
+  void print_stencil_dagger_site(int x, int y, string prefix = "") {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call print_stencil_dagger_site, but the dagger stencil has not been allocated.\n"; return; }
+    perform_swap_dagger(); print_stencil_site(x, y, prefix); perform_swap_dagger();
+  }
+
+#define QMG_DAGGER_GUARD(fn, piece, what)                                                                                         \
+  if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call " fn ", but the dagger stencil has not been allocated.\n"; return; } \
+  if ((piece) == 0) { cout << "[QMG-WARNING]: Tried to call " fn ", but the dagger " what " does not exist.\n"; return; }
+
+  void apply_M_dagger_clover(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_clover", dagger_clover, "clover") perform_swap_dagger(); apply_M_clover(lhs, rhs); perform_swap_dagger(); }
+  void apply_M_dagger_ee(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_ee", dagger_clover, "clover") perform_swap_dagger(); apply_M_ee(lhs, rhs); perform_swap_dagger(); }
+  void apply_M_dagger_oo(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_oo", dagger_clover, "clover") perform_swap_dagger(); apply_M_oo(lhs, rhs); perform_swap_dagger(); }
+  void apply_M_dagger_eo(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_eo", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_eo(lhs, rhs); perform_swap_dagger(); }
+  void apply_M_dagger_eo(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { QMG_DAGGER_GUARD("apply_M_dagger_eo", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_eo(lhs, rhs, dir); perform_swap_dagger(); }
+  void apply_M_dagger_oe(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_oe", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_oe(lhs, rhs); perform_swap_dagger(); }
+  void apply_M_dagger_oe(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { QMG_DAGGER_GUARD("apply_M_dagger_oe", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_oe(lhs, rhs, dir); perform_swap_dagger(); }
+  void apply_M_dagger_hopping(complex<double>* lhs, complex<double>* rhs) { QMG_DAGGER_GUARD("apply_M_dagger_hopping", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_hopping(lhs, rhs); perform_swap_dagger(); }
+  // The reference ignores `dir` here and applies all four directions (:1362-1364); behaviour kept.
+  void apply_M_dagger_hopping(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { QMG_DAGGER_GUARD("apply_M_dagger_hopping", dagger_hopping, "hopping term") perform_swap_dagger(); apply_M_hopping(lhs, rhs); perform_swap_dagger(); }
+#undef QMG_DAGGER_GUARD
+
+  void apply_M_dagger_shift(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_dagger_shift, but the dagger stencil has not been allocated.\n"; return; }
+    perform_swap_dagger(); apply_M_shift(lhs, rhs); perform_swap_dagger();
+  }
+  void apply_M_dagger(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_dagger, but the dagger stencil has not been allocated.\n"; return; }
+    perform_swap_dagger(); apply_M(lhs, rhs); perform_swap_dagger();
+  }
+  void apply_M_dagger_M(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_dagger_M, but the dagger stencil has not been built.\n"; return; }
+    apply_M_overwrite(extra_cvector, rhs);
+    apply_M_dagger(lhs, extra_cvector);
+  }
+  void prepare_M_dagger_M(complex<double>* Mdagger_b, complex<double>* b) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call prepare_M_dagger_M, but the dagger stencil has not been built.\n"; return; }
+    apply_M_dagger(Mdagger_b, b);
+  }
+  void apply_M_M_dagger(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_M_dagger, but the dagger stencil has not been built.\n"; return; }
+    zero_vector(extra_cvector, lat->get_size_cv_l());
+    apply_M_dagger(extra_cvector, rhs);
+    apply_M(lhs, extra_cvector);
+  }
+  void reconstruct_M_M_dagger(complex<double>* x, complex<double>* y) {
+    if (!built_dagger) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_M_dagger, but the dagger stencil has not been built.\n"; return; }
+    apply_M_dagger(x, y);
+  }
+
+  // ================= right block Jacobi (:1452-1983) =================
+  void build_rbjacobi_stencil() {
+    if (built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call build_rbjacobi_stencil, but it's already been called once.\n"; return; }
+    if (clover == 0 && shift == 0.0 && eo_shift == 0.0 && dof_shift == 0.0) {
+      std::cout << "[QMG-ERROR]: Tried to call build_rbjacobi_stencil, but there is no clover term or shift.\n";
+      return;
+    }
+    rbjacobi_cinv = allocate_vector<complex<double>>(lat->get_size_cm_l());
+    rbjacobi_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
+    if (hopping != 0) rbjacobi_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
+    qmg_stencil_desc d = desc();
+    qmg::ok(qmg_build_rbjacobi(rbjacobi_cinv, rbjacobi_clover, rbjacobi_hopping, &d, qmg::current_stream()), "qmg_build_rbjacobi");
+    if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
+    if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
+    built_rbjacobi = true;
+  }
+
+  bool perform_swap_rbjacobi() {   // :1604-1639
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call perform_swap_rbjacobi, but the rbjacobi stencil has not been allocated.\n"; return false; }
+    std::swap(clover, rbjacobi_clover); std::swap(hopping, rbjacobi_hopping);
+    std::swap(twolink, rbjacobi_twolink); std::swap(corner, rbjacobi_corner);
+    if (!swap_rbjacobi) { shift = 0.0; eo_shift = 0.0; dof_shift = 0.0; swap_rbjacobi = true; }
+    else { shift = shift_backup; eo_shift = eo_shift_backup; dof_shift = dof_shift_backup; swap_rbjacobi = false; }
+    return swap_rbjacobi;
+  }
+
+  void print_stencil_rbjacobi_site(int x, int y, string prefix = "") {
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call print_stencil_rbjacobi_site, but the rbjacobi stencil has not been allocated.\n"; return; }
+    perform_swap_rbjacobi();
+    print_stencil_site(x, y, prefix);
+    if (clover != 0) {
+      cout << prefix << "Right Block Jacobi Inv Clover\n";
+      const int nc = lat->get_nc();
+      std::vector<complex<double>> m = qmg::to_host(rbjacobi_cinv + lat->cm_coord_to_index(x, y, 0, 0), (size_t)nc * nc);
+      for (int i = 0; i < nc; i++) { cout << prefix; for (int j = 0; j < nc; j++) cout << m[i * nc + j] << " "; cout << "\n"; }
+    }
+    perform_swap_rbjacobi();
+  }
+
+#define QMG_RBJ_GUARD(fn, piece, what)                                                                                               \
+  if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call " fn ", but the rbjacobi stencil has not been allocated.\n"; return; } \
+  if ((piece) == 0) { cout << "[QMG-WARNING]: Tried to call " fn ", but the rbjacobi " what " does not exist.\n"; return; }
+
+  // the rbjacobi clover is the identity (:1684-1685)
+  void apply_M_rbjacobi_clover(complex<double>* lhs, complex<double>* rhs) { QMG_RBJ_GUARD("apply_M_rbjacobi_clover", rbjacobi_clover, "clover") cxpy(rhs, lhs, lat->get_size_cv_l()); }
+  void apply_M_rbjacobi_eo(complex<double>* lhs, complex<double>* rhs) { QMG_RBJ_GUARD("apply_M_rbjacobi_eo", rbjacobi_hopping, "hopping term") launch(QMG_P_EO, lhs, rhs, 0, swap_rbjacobi ? hopping : rbjacobi_hopping, 0.0, 0.0, 0.0); }
+  void apply_M_rbjacobi_eo(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { QMG_RBJ_GUARD("apply_M_rbjacobi_eo", rbjacobi_hopping, "hopping term") launch(QMG_P_EO_XP1 << (int)dir, lhs, rhs, 0, swap_rbjacobi ? hopping : rbjacobi_hopping, 0.0, 0.0, 0.0); }
+  void apply_M_rbjacobi_oe(complex<double>* lhs, complex<double>* rhs) { QMG_RBJ_GUARD("apply_M_rbjacobi_oe", rbjacobi_hopping, "hopping term") launch(QMG_P_OE, lhs, rhs, 0, swap_rbjacobi ? hopping : rbjacobi_hopping, 0.0, 0.0, 0.0); }
+  void apply_M_rbjacobi_oe(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { QMG_RBJ_GUARD("apply_M_rbjacobi_oe", rbjacobi_hopping, "hopping term") launch(QMG_P_OE_XP1 << (int)dir, lhs, rhs, 0, swap_rbjacobi ? hopping : rbjacobi_hopping, 0.0, 0.0, 0.0); }
+  void apply_M_rbjacobi_hopping(complex<double>* lhs, complex<double>* rhs) { QMG_RBJ_GUARD("apply_M_rbjacobi_hopping", rbjacobi_hopping, "hopping term") launch(QMG_P_HOPPING, lhs, rhs, 0, swap_rbjacobi ? hopping : rbjacobi_hopping, 0.0, 0.0, 0.0); }
+  // `dir` ignored by the reference (:1797-1799); behaviour kept.
+  void apply_M_rbjacobi_hopping(complex<double>* lhs, complex<double>* rhs, stencil_dir_index dir) { apply_M_rbjacobi_hopping(lhs, rhs); }
+#undef QMG_RBJ_GUARD
+
+  void apply_M_rbjacobi_shift(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_shift, but the rbjacobi stencil has not been allocated.\n"; return; }
+  }
+
+  // lhs += (1 + H') rhs in ONE launch: the identity clover is applied as a unit shift, so the
+  // identity matrices are never read (4/5 of the reference's matrix traffic).
+  void apply_M_rbjacobi(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi, but the rbjacobi stencil has not been allocated.\n"; return; }
+    const complex<double>* rh = swap_rbjacobi ? hopping : rbjacobi_hopping;
+    launch(QMG_P_HOPPING | QMG_P_SHIFT, lhs, rhs, 0, rh, 1.0, 0.0, 0.0);
+  }
+
+  void apply_M_rbjacobi_cinv(complex<double>* lhs, complex<double>* rhs) {   // :1848-1866
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_cinv, but the rbjacobi stencil has not been allocated.\n"; return; }
+    if (rbjacobi_cinv == 0) { cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_cinv, but the rbjacobi cinv does not exist.\n"; return; }
+    launch(QMG_P_CLOVER, lhs, rhs, rbjacobi_cinv, 0, 0.0, 0.0, 0.0);
+  }
+  void reconstruct_M_rbjacobi(complex<double>* x, complex<double>* y) {
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_rbjacobi_cinv, but the rbjacobi stencil has not been allocated.\n"; return; }
+    apply_M_rbjacobi_cinv(x, y);
+  }
+
+  // Schur complement  lhs_e = rhs_e - D'_eo D'_oe rhs_e  (:1886-1908)
+  void apply_M_rbjacobi_schur(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_schur, but the rbjacobi stencil has not been allocated.\n"; return; }
+    if (eo_cvector == 0) eo_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
+    const complex<double>* rh = swap_rbjacobi ? hopping : rbjacobi_hopping;
+    const long half = lat->get_size_cv_l() / 2;
+    // odd half of the scratch = D'_oe rhs_e (overwrite); even half = D'_eo of that (overwrite); then the axpbyz
+    launch(QMG_P_OE | QMG_P_ZERO_O, eo_cvector, rhs, 0, rh, 0.0, 0.0, 0.0);
+    launch(QMG_P_EO | QMG_P_ZERO_E, eo_cvector, eo_cvector, 0, rh, 0.0, 0.0, 0.0);
+    caxpbyz(1.0, rhs, -1.0, eo_cvector, lhs, half);
+  }
+  void prepare_M_rbjacobi_schur(complex<double>* b_r, complex<double>* b) {   // :1912-1928
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call prepare_M_rbjacobi_schur, but the rbjacobi stencil has not been allocated.\n"; return; }
+    const long half = lat->get_size_cv_l() / 2;
+    apply_M_rbjacobi_eo(b_r, b);
+    cxpay(b, -1.0, b_r, half);
+    zero_vector(b_r + half, half);
+  }
+  void reconstruct_M_rbjacobi_schur(complex<double>* x, complex<double>* y_e, complex<double>* b) {   // :1932-1957
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_rbjacobi_schur, but the rbjacobi stencil has not been allocated.\n"; return; }
+    if (eo_cvector == 0) eo_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
+    const long half = lat->get_size_cv_l() / 2;
+    const complex<double>* rh = swap_rbjacobi ? hopping : rbjacobi_hopping;
+    launch(QMG_P_OE | QMG_P_ZERO_O, eo_cvector, y_e, 0, rh, 0.0, 0.0, 0.0);
+    cxpay(b + half, -1.0, eo_cvector + half, half);
+    copy_vector(eo_cvector, y_e, half);
+    apply_M_rbjacobi_cinv(x, eo_cvector);
+  }
+  void reconstruct_M_rbjacobi_schur_to_rbjacobi(complex<double>* x, complex<double>* y_e, complex<double>* b) {   // :1961-1983
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_rbjacobi_schur_to_rbjacobi, but the rbjacobi stencil has not been allocated.\n"; return; }
+    if (eo_cvector == 0) eo_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
+    const long half = lat->get_size_cv_l() / 2;
+    const complex<double>* rh = swap_rbjacobi ? hopping : rbjacobi_hopping;
+    launch(QMG_P_OE | QMG_P_ZERO_O, eo_cvector, y_e, 0, rh, 0.0, 0.0, 0.0);
+    caxpbyz(1.0, b + half, -1.0, eo_cvector + half, x + half, half);
+    copy_vector(x, y_e, half);
+  }
+
+  // ================= rbjacobi dagger (:1989-2411) =================
+  void build_rbj_dagger_stencil() {
+    if (built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call build_rbj_dagger_stencil, but it's already been called once.\n"; return; }
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call build_rbj_dagger_stencil, but the right jacobi stencil has not been built yet.\n"; return; }
+    const int Lx = lat->get_dim_mu(0), Ly = lat->get_dim_mu(1), nc = lat->get_nc();
+    if (rbjacobi_clover != 0) rbj_dagger_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
+    if (rbjacobi_hopping != 0) rbj_dagger_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
+    qmg::ok(qmg_build_dagger(rbj_dagger_clover, rbj_dagger_hopping, rbjacobi_clover, rbjacobi_hopping, Lx, Ly, nc, qmg::current_stream()), "qmg_build_dagger");
+    if (rbjacobi_cinv != 0) {
+      rbj_dagger_cinv = allocate_vector<complex<double>>(lat->get_size_cm_l());
+      qmg::ok(qmg_cmat_conjtrans(rbj_dagger_cinv, rbjacobi_cinv, (size_t)lat->get_volume(), nc, qmg::current_stream()), "qmg_cmat_conjtrans");
+    }
+    built_rbj_dagger = true;
+  }
+
+  bool perform_swap_rbj_dagger() {   // :2063-2098
+    if (!built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call perform_swap_rbj_dagger, but the right jacobi dagger stencil has not been allocated.\n"; return false; }
+    std::swap(clover, rbj_dagger_clover); std::swap(hopping, rbj_dagger_hopping);
+    std::swap(twolink, rbj_dagger_twolink); std::swap(corner, rbj_dagger_corner);
+    if (!swap_rbj_dagger) { shift = 0.0; eo_shift = 0.0; dof_shift = 0.0; swap_rbj_dagger = true; }
+    else { shift = shift_backup; eo_shift = eo_shift_backup; dof_shift = dof_shift_backup; swap_rbj_dagger = false; }
+    return swap_rbj_dagger;
+  }
+
+  void apply_M_rbj_dagger(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbj_dagger, but the right jacobi dagger stencil has not been allocated.\n"; return; }
+    const complex<double>* rh = swap_rbj_dagger ? hopping : rbj_dagger_hopping;
+    launch(QMG_P_HOPPING | QMG_P_SHIFT, lhs, rhs, 0, rh, 1.0, 0.0, 0.0);   // identity clover as a unit shift
+  }
+  void apply_M_rbj_dagger_cinv(complex<double>* lhs, complex<double>* rhs) {
+    if (!built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbj_dagger_cinv, but the right jacobi dagger stencil has not been allocated.\n"; return; }
+    launch(QMG_P_CLOVER, lhs, rhs, rbj_dagger_cinv, 0, 0.0, 0.0, 0.0);
+  }
+  void apply_M_rbjacobi_MDM(complex<double>* lhs, complex<double>* rhs) {   // :2282-2299
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_MDM, but the right jacobi stencil has not been built.\n"; return; }
+    if (!built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_MDM, but the right jacobi dagger stencil has not been built.\n"; return; }
+    zero_vector(extra_cvector, lat->get_size_cv_l());
+    apply_M_rbjacobi(extra_cvector, rhs);
+    apply_M_rbj_dagger(lhs, extra_cvector);
+  }
+  void prepare_M_rbjacobi_MDM(complex<double>* Mdagger_b, complex<double>* b) {
+    if (!built_rbjacobi || !built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call prepare_M_rbjacobi_MDM, but the right jacobi (dagger) stencil has not been built.\n"; return; }
+    apply_M_rbj_dagger(Mdagger_b, b);
+  }
+  void reconstruct_M_rbjacobi_MDM(complex<double>* x, complex<double>* y) {
+    if (!built_rbjacobi || !built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_rbjacobi_MDM, but the right jacobi (dagger) stencil has not been built.\n"; return; }
+    apply_M_rbjacobi_cinv(x, y);
+  }
+  void apply_M_rbjacobi_MMD(complex<double>* lhs, complex<double>* rhs) {   // :2354-2371
+    if (!built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_MMD, but the right jacobi stencil has not been built.\n"; return; }
+    if (!built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_MMD, but the right jacobi dagger stencil has not been built.\n"; return; }
+    zero_vector(extra_cvector, lat->get_size_cv_l());
+    apply_M_rbj_dagger(extra_cvector, rhs);
+    apply_M_rbjacobi(lhs, extra_cvector);
+  }
+  void reconstruct_M_rbjacobi_MMD(complex<double>* x, complex<double>* y) {   // :2373-2392
+    if (!built_rbjacobi || !built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call reconstruct_M_rbjacobi_MMD, but the right jacobi (dagger) stencil has not been built.\n"; return; }
+    zero_vector(x, lat->get_size_cv_l());
+    apply_M_rbj_dagger(x, y);
+    zero_vector(extra_cvector, lat->get_size_cv_l());
+    apply_M_rbjacobi_cinv(extra_cvector, x);
+    copy_vector(x, extra_cvector, lat->get_size_cv_l());
+  }
+
+  // ================= dispatch by type (:2418-2566) =================
+  void apply_M(complex<double>* lhs, complex<double>* rhs, QMGStencilType stencil) {
+    switch (stencil) {
+      case QMG_MATVEC_ORIGINAL: apply_M(lhs, rhs); break;
+      case QMG_MATVEC_DAGGER: apply_M_dagger(lhs, rhs); break;
+      case QMG_MATVEC_RIGHT_JACOBI: apply_M_rbjacobi(lhs, rhs); break;
+      case QMG_MATVEC_RIGHT_SCHUR: apply_M_rbjacobi_schur(lhs, rhs); break;
+      case QMG_MATVEC_M_MDAGGER: apply_M_M_dagger(lhs, rhs); break;
+      case QMG_MATVEC_MDAGGER_M: apply_M_dagger_M(lhs, rhs); break;
+      case QMG_MATVEC_RBJ_DAGGER: apply_M_rbj_dagger(lhs, rhs); break;
+      case QMG_MATVEC_RBJ_M_MDAGGER: apply_M_rbjacobi_MMD(lhs, rhs); break;
+      case QMG_MATVEC_RBJ_MDAGGER_M: apply_M_rbjacobi_MDM(lhs, rhs); break;
+      default: cout << "[QMG-ERROR]: Tried to call apply_M with invalid stencil type.\n"; break;
+    }
+  }
+  void prepare_M(complex<double>* b_prep, complex<double>* b, QMGStencilType stencil) {
+    const long cv = lat->get_size_cv_l();
+    switch (stencil) {
+      case QMG_MATVEC_RIGHT_SCHUR: prepare_M_rbjacobi_schur(b_prep, b); break;
+      case QMG_MATVEC_MDAGGER_M: prepare_M_dagger_M(b_prep, b); break;
+      case QMG_MATVEC_RBJ_MDAGGER_M: prepare_M_rbjacobi_MDM(b_prep, b); break;
+      case QMG_MATVEC_ORIGINAL: case QMG_MATVEC_DAGGER: case QMG_MATVEC_RIGHT_JACOBI: case QMG_MATVEC_M_MDAGGER:
+      case QMG_MATVEC_RBJ_DAGGER: case QMG_MATVEC_RBJ_M_MDAGGER: copy_vector(b_prep, b, cv); break;
+      default: cout << "[QMG-ERROR]: Tried to call prepare_M with invalid stencil type.\n"; break;
+    }
+  }
+  void reconstruct_M(complex<double>* x, complex<double>* y, complex<double>* b, QMGStencilType stencil) {
+    const long cv = lat->get_size_cv_l();
+    switch (stencil) {
+      case QMG_MATVEC_RIGHT_JACOBI: reconstruct_M_rbjacobi(x, y); break;
+      case QMG_MATVEC_RIGHT_SCHUR: reconstruct_M_rbjacobi_schur(x, y, b); break;
+      case QMG_MATVEC_M_MDAGGER: reconstruct_M_M_dagger(x, y); break;
+      case QMG_MATVEC_RBJ_M_MDAGGER: reconstruct_M_rbjacobi_MMD(x, y); break;
+      case QMG_MATVEC_RBJ_MDAGGER_M: reconstruct_M_rbjacobi_MDM(x, y); break;
+      case QMG_MATVEC_ORIGINAL: case QMG_MATVEC_DAGGER: case QMG_MATVEC_MDAGGER_M: case QMG_MATVEC_RBJ_DAGGER: copy_vector(x, y, cv); break;
+      default: cout << "[QMG-ERROR]: Tried to call reconstruct_M with invalid stencil type.\n"; break;
+    }
+  }
+  static matrix_op_cplx get_apply_function(QMGStencilType stencil) {
+    switch (stencil) {
+      case QMG_MATVEC_ORIGINAL: return apply_stencil_2D_M;
+      case QMG_MATVEC_DAGGER: return apply_stencil_2D_M_dagger;
+      case QMG_MATVEC_RIGHT_JACOBI: return apply_stencil_2D_M_rbjacobi;
+      case QMG_MATVEC_RIGHT_SCHUR: return apply_stencil_2D_M_rbjacobi_schur;
+      case QMG_MATVEC_M_MDAGGER: return apply_stencil_2D_M_M_dagger;
+      case QMG_MATVEC_MDAGGER_M: return apply_stencil_2D_M_dagger_M;
+      case QMG_MATVEC_RBJ_DAGGER: return apply_stencil_2D_M_rbj_dagger;
+      case QMG_MATVEC_RBJ_M_MDAGGER: return apply_stencil_2D_M_rbjacobi_MMD;
+      case QMG_MATVEC_RBJ_MDAGGER_M: return apply_stencil_2D_M_rbjacobi_MDM;
+      default: cout << "[QMG-ERROR]: Tried to call get_apply_function with invalid stencil type.\n"; return 0;
+    }
+  }
+};
+
+// ================= C wrappers (stencil_2d.h:2571-2716): lhs = M rhs, device pointers =================
+inline void apply_stencil_2D_M(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  ((Stencil2D*)extra_data)->apply_M_overwrite(lhs, rhs);   // zero_vector + apply_M fused
+}
+inline void apply_stencil_2D_M_piece_clover(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_clover(lhs, rhs);
+}
+inline void apply_stencil_2D_M_piece_hopping(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_hopping(lhs, rhs);
+}
+inline void apply_stencil_2D_M_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  zero_vector(lhs, s->lat->get_size_cv_l());   // zeroed BEFORE the guard, as the reference does (:2597-2602)
+  if (!s->built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_dagger, but the dagger stencil has not been built.\n"; return; }
+  s->apply_M_dagger(lhs, rhs);
+}
+inline void apply_stencil_2D_M_dagger_M(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_dagger_M, but the dagger stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_dagger_M(lhs, rhs);
+}
+inline void apply_stencil_2D_M_M_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_M_dagger, but the dagger stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_M_dagger(lhs, rhs);
+}
+inline void apply_stencil_2D_M_rbjacobi(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbjacobi, but the rbjacobi stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_rbjacobi(lhs, rhs);
+}
+inline void apply_stencil_2D_M_rbjacobi_cinv(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbjacobi_cinv, but the rbjacobi stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_rbjacobi_cinv(lhs, rhs);
+}
+inline void apply_stencil_2D_M_rbjacobi_schur(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbjacobi_schur, but the rbjacobi stencil has not been built.\n"; return; }
+  s->apply_M_rbjacobi_schur(lhs, rhs);   // writes lhs_e outright (caxpbyz), so the reference's half zero_vector (:2668) is subsumed
+}
+inline void apply_stencil_2D_M_rbj_dagger(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbj_dagger, but the rbjacobi dagger stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_rbj_dagger(lhs, rhs);
+}
+inline void apply_stencil_2D_M_rbjacobi_MMD(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbjacobi || !s->built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbjacobi_MMD, but the rbjacobi (dagger) stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_rbjacobi_MMD(lhs, rhs);
+}
+inline void apply_stencil_2D_M_rbjacobi_MDM(complex<double>* lhs, complex<double>* rhs, void* extra_data) {
+  Stencil2D* s = (Stencil2D*)extra_data;
+  if (!s->built_rbjacobi || !s->built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_stencil_2D_M_rbjacobi_MDM, but the rbjacobi (dagger) stencil has not been built.\n"; return; }
+  zero_vector(lhs, s->lat->get_size_cv_l());
+  s->apply_M_rbjacobi_MDM(lhs, rhs);
+}
+
+// Host-pointer compatibility thunk with the exact matrix_op_cplx signature, for an UNMODIFIED host
+// solver (e.g. quantum-linalg running on the CPU): stages rhs to HBM, applies on the GPU, copies lhs back.
+// PCIe-bound by construction; the device-pointer wrappers above are the real path.
+struct HostThunkData { Stencil2D* stencil; matrix_op_cplx device_op; complex<double>*dev_lhs, *dev_rhs; };
+inline void apply_stencil_2D_host_thunk(complex<double>* lhs_host, complex<double>* rhs_host, void* extra_data) {
+  HostThunkData* t = (HostThunkData*)extra_data;
+  const size_t n = (size_t)t->stencil->lat->get_size_cv_l();
+  qmg::upload(t->dev_rhs, rhs_host, n);
+  t->device_op(t->dev_lhs, t->dev_rhs, (void*)t->stencil);
+  qmg::download(lhs_host, t->dev_lhs, n);
+}
+
+#endif

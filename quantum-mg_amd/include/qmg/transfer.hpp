@@ -1,0 +1,140 @@
+// transfer.hpp -- TransferMG on device arrays (reference: transfer/transfer.h:42-820).
+// The null vectors live in ONE contiguous device allocation, vector-major (d, fine cv index), which is
+// exactly the reference's `null_vectors[d][k]` with a fixed stride; `null_vectors[d]` pointers into it
+// are exposed for code that indexes them the reference way.  The one-to-many `coarse_map` of the
+// reference (:410-448) is not materialised: the kernels derive the block of a fine element from its
+// position (regular rectangular blocks).
+#ifndef QMG_TRANSFER_HPP
+#define QMG_TRANSFER_HPP
+
+#include <iostream>
+
+#include "lattice2d.hpp"
+#include "qmg_device.hpp"
+
+enum QMGDoublingType { QMG_DOUBLE_NONE = 0, QMG_DOUBLE_PROJECTION = 1, QMG_DOUBLE_OPERATOR = 2 };
+
+class TransferMG {
+ private:
+  TransferMG(TransferMG const&);
+  TransferMG& operator=(TransferMG const&);
+
+  Lattice2D* fine_lat;
+  Lattice2D* coarse_lat;
+  int const_num_null_vec;
+  int blocksizes[2];
+  int fine_sites_per_coarse;
+  complex<double>* null_store;       // nvec * fine_size_cv, contiguous
+  complex<double>* restrict_store;   // same for an asymmetric restrictor, or 0
+  QMGDoublingType doubling;
+  bool is_init;
+
+  bool geometry_ok() {
+    fine_sites_per_coarse = fine_lat->get_nc();
+    for (int i = 0; i < 2; i++) {
+      if (fine_lat->get_dim_mu(i) % coarse_lat->get_dim_mu(i) != 0) {
+        std::cout << "[QMG-ERROR]: Fine lattice dimension " << i << "isn't divided evenly by coarse dimension.\n";
+        return false;
+      }
+      blocksizes[i] = fine_lat->get_dim_mu(i) / coarse_lat->get_dim_mu(i);
+      fine_sites_per_coarse *= blocksizes[i];
+    }
+    return true;
+  }
+  complex<double>* copy_in(complex<double>** vecs) {
+    const long fsize = fine_lat->get_size_cv_l();
+    complex<double>* store = allocate_vector<complex<double>>((size_t)const_num_null_vec * fsize);
+    for (int i = 0; i < const_num_null_vec; i++) copy_vector(store + i * fsize, vecs[i], fsize);
+    return store;
+  }
+  void one_ortho_pass(complex<double>* chol) {
+    qmg::ok(qmg_block_orthonormalize(null_store, const_num_null_vec, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
+                                     coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), chol, qmg::current_stream()),
+            "qmg_block_orthonormalize");
+  }
+
+ public:
+  complex<double>** null_vectors;            // null_vectors[d] -> device vector d (views into one allocation)
+  complex<double>** restrict_null_vectors;   // 0 when the restrictor is P^dagger
+  complex<double>* block_cholesky;           // device, coarse size_cm, or 0
+  complex<double>* block_L;
+  complex<double>* block_U;
+
+  // transfer.h:118-179.  in_null_vectors[d]: device vectors; they are copied (the caller keeps ownership).
+  TransferMG(Lattice2D* in_fine_lat, Lattice2D* in_coarse_lat, complex<double>** in_null_vectors, bool do_block_ortho = true,
+             bool save_decomp = false, QMGDoublingType in_doubling = QMG_DOUBLE_NONE)
+      : fine_lat(in_fine_lat), coarse_lat(in_coarse_lat), const_num_null_vec(in_coarse_lat->get_nc()), null_store(0), restrict_store(0),
+        doubling(in_doubling), is_init(false), null_vectors(0), restrict_null_vectors(0), block_cholesky(0), block_L(0), block_U(0) {
+    if (!geometry_ok()) return;
+    null_store = copy_in(in_null_vectors);
+    null_vectors = new complex<double>*[const_num_null_vec];
+    for (int i = 0; i < const_num_null_vec; i++) null_vectors[i] = null_store + (long)i * fine_lat->get_size_cv_l();
+    if (save_decomp) {
+      block_cholesky = allocate_vector<complex<double>>(coarse_lat->get_size_cm_l());
+      zero_vector(block_cholesky, coarse_lat->get_size_cm_l());
+    }
+    if (do_block_ortho) {   // twice; the decomposition is saved on the first pass only (:160-174)
+      one_ortho_pass(block_cholesky);
+      one_ortho_pass(0);
+    }
+    is_init = true;
+  }
+
+  // Separate prolongator / restrictor (:185-230).  Block BI-orthonormalisation (:610-769) is not built yet:
+  // the vectors are used as given and a request for it is reported.
+  TransferMG(Lattice2D* in_fine_lat, Lattice2D* in_coarse_lat, complex<double>** in_prolong_null_vectors,
+             complex<double>** in_restrict_null_vectors, bool do_block_bi_ortho = true, bool save_decomp = false,
+             QMGDoublingType in_doubling = QMG_DOUBLE_NONE)
+      : TransferMG(in_fine_lat, in_coarse_lat, in_prolong_null_vectors, false, false, in_doubling) {
+    if (!is_init) return;
+    restrict_store = copy_in(in_restrict_null_vectors);
+    restrict_null_vectors = new complex<double>*[const_num_null_vec];
+    for (int i = 0; i < const_num_null_vec; i++) restrict_null_vectors[i] = restrict_store + (long)i * fine_lat->get_size_cv_l();
+    if (do_block_bi_ortho || save_decomp)
+      std::cout << "[QMG-ERROR]: TransferMG: block bi-orthonormalization is not available on the device path yet; vectors used as given.\n";
+  }
+
+  ~TransferMG() {
+    if (null_vectors) delete[] null_vectors;
+    if (restrict_null_vectors) delete[] restrict_null_vectors;
+    if (null_store) deallocate_vector(&null_store);
+    if (restrict_store) deallocate_vector(&restrict_store);
+    if (block_cholesky) deallocate_vector(&block_cholesky);
+    if (block_L) deallocate_vector(&block_L);
+    if (block_U) deallocate_vector(&block_U);
+  }
+
+  bool is_initialized() { return is_init; }
+
+  // fine += P coarse (:283-286, 455-480): accumulates, caller zeroes
+  void prolong_c2f(complex<double>* coarse_cv, complex<double>* fine_cv) {
+    qmg::ok(qmg_prolong(null_store, const_num_null_vec, coarse_cv, fine_cv, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
+                        coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), qmg::current_stream()), "qmg_prolong");
+  }
+  // coarse += R fine (:291-294, 487-511)
+  void restrict_f2c(complex<double>* fine_cv, complex<double>* coarse_cv) {
+    qmg::ok(qmg_restrict(restrict_store ? restrict_store : null_store, const_num_null_vec, fine_cv, coarse_cv, fine_lat->get_dim_mu(0),
+                         fine_lat->get_dim_mu(1), fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(),
+                         qmg::current_stream()), "qmg_restrict");
+  }
+
+  bool is_symmetric() { return restrict_store == 0; }
+  bool has_decompositions() { return is_symmetric() ? (block_cholesky != 0) : (block_L != 0 && block_U != 0); }
+  void copy_cholesky(complex<double>* save_cholesky) {
+    if (block_cholesky == 0) std::cout << "[QMG-WARNING]: In expose_cholesky, block Cholesky has not been computed.\n";
+    else copy_vector(save_cholesky, block_cholesky, coarse_lat->get_size_cm_l());
+  }
+  void copy_LU(complex<double>* save_L, complex<double>* save_U) {
+    if (block_L == 0 || block_U == 0) std::cout << "[QMG-WARNING]: In expose_LU, block LU has not been computed.\n";
+    else { copy_vector(save_L, block_L, coarse_lat->get_size_cm_l()); copy_vector(save_U, block_U, coarse_lat->get_size_cm_l()); }
+  }
+  QMGDoublingType get_doubling() { return doubling; }
+
+  // for the coarse-operator build
+  const complex<double>* device_null_vectors() const { return null_store; }
+  const complex<double>* device_restrict_vectors() const { return restrict_store; }
+  Lattice2D* get_fine_lattice() { return fine_lat; }
+  Lattice2D* get_coarse_lattice() { return coarse_lat; }
+};
+
+#endif
