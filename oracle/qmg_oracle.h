@@ -121,6 +121,12 @@ int qo_coarse_build(double* cclover, double* chopping, const qo_stencil_desc* fi
                     const double* nullvecs, const double* restrict_vecs /*or NULL*/,
                     int cLx, int cLy, int cnc);
 
+/* ---- K-cycle (oracle/qmg_oracle_kcycle.cpp): multigrid/stateful_multigrid.h:734-1060 driven as
+ *      tests/n13_wilson_kcycle/wilson_kcycle.cpp:86-122,459-471.  Krylov drivers: parity unpinned. ---- */
+int qo_wilson_kcycle(int L, double mass, int n_refine, int coarse_dof, const double* gauge, const double* const* nullvecs, const double* b,
+                     double tol, int max_iter, int restart, double inner_tol, double coarsest_tol, int n_smooth, double* x_out,
+                     double* true_res, long* ops, long* its);
+
 /* ---- timing helper for bench.py's cpu_baseline leg ---- */
 double qo_time_apply(const qo_stencil_desc* d, double* lhs, const double* rhs, unsigned pieces, int reps);
 

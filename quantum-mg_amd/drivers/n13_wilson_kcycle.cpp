@@ -12,8 +12,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <iomanip>
+#include <cstdio>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../include/qmg/qmg.hpp"
 
@@ -35,6 +37,7 @@ int main(int argc, char** argv) {
   const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
   const int tile = (argc > 7) ? stoi(argv[7]) : 64;
   const bool quiet = getenv("QMG_QUIET") != 0;
+  const char* dump_dir = getenv("QMG_DUMP_DIR");   // test hook: null vectors, rhs and solution as raw complex128
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4;
   const double tol = 1e-10; const int max_iter = 1000; const int restart_freq = 32;
@@ -97,6 +100,15 @@ int main(int argc, char** argv) {
       normalize(null_vectors[j], fsize);
       normalize(null_vectors[j + lats[i]->get_nc() / 2], fsize);
     }
+    if (dump_dir) {   // raw complex128, coarse_dof vectors back to back (pre block-ortho), for the parity test
+      std::string path = std::string(dump_dir) + "/nullvecs_level" + std::to_string(i - 1) + ".bin";
+      FILE* f = fopen(path.c_str(), "wb");
+      for (int j = 0; j < coarse_dof; j++) {
+        std::vector<complex<double>> h = qmg::to_host(null_vectors[j], (size_t)fsize);
+        fwrite(h.data(), sizeof(complex<double>), h.size(), f);
+      }
+      fclose(f);
+    }
     transfer_objs[i - 1] = new TransferMG(lats[i - 1], lats[i], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
     level_solve_objs[i - 1] = new StatefulMultigridMG::LevelSolveMG;
     level_solve_objs[i - 1]->fine_stencil_app = QMG_MATVEC_ORIGINAL;
@@ -134,6 +146,12 @@ int main(int argc, char** argv) {
   mg_object->apply_stencil(Ax, x, 0);
   const double true_res = sqrt(diffnorm2sq(b, Ax, lats[0]->get_size_cv_l())) / bnorm;
   cout << "Check tolerance " << true_res << "\n";
+  if (dump_dir) {
+    const size_t n = (size_t)lats[0]->get_size_cv_l();
+    std::vector<complex<double>> hb = qmg::to_host(b, n), hx = qmg::to_host(x, n);
+    FILE* f = fopen((std::string(dump_dir) + "/b.bin").c_str(), "wb"); fwrite(hb.data(), sizeof(complex<double>), n, f); fclose(f);
+    f = fopen((std::string(dump_dir) + "/x.bin").c_str(), "wb"); fwrite(hx.data(), sizeof(complex<double>), n, f); fclose(f);
+  }
   cout << setprecision(6);
   for (int i = 0; i <= n_refine; i++)
     cout << "[QMG-OPS-STATS]: Level " << i << " NullVec " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_NULLVEC, i) << " PreSmooth "

@@ -32,7 +32,7 @@ class StencilDesc(C.Structure):
 
 def build():
     """(Re)build the oracle with its Makefile if the .so is missing or stale."""
-    src = [os.path.join(ORACLE_DIR, f) for f in ("qmg_oracle.cpp", "qmg_oracle.h", "Makefile")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("qmg_oracle.cpp", "qmg_oracle_kcycle.cpp", "qmg_oracle.h", "Makefile")]
     if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libqmg_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -234,3 +234,16 @@ def coarse_build(fdesc, nullvecs, cdims, restrict_vecs=None):
     rc = lib().qo_coarse_build(_p(cclover), _p(chopping), C.byref(fdesc), _p(nullvecs), _p(restrict_vecs), cLx, cLy, cnc)
     assert rc == 0, rc
     return cclover, chopping
+
+
+def wilson_kcycle(L, mass, n_refine, coarse_dof, gauge, nullvecs, b, tol=1e-10, max_iter=1000, restart=32, inner_tol=0.2,
+                  coarsest_tol=0.2, n_smooth=2):
+    """CPU K-cycle solve (oracle/qmg_oracle_kcycle.cpp). nullvecs: list of per-level arrays (coarse_dof x level size)."""
+    ptrs = (C.c_void_p * n_refine)(*[nv.ctypes.data for nv in nullvecs])
+    x = cvec(L * L * 2)
+    true_res = C.c_double()
+    ops = (C.c_long * (n_refine + 1))()
+    its = (C.c_long * (n_refine + 1))()
+    it = lib().qo_wilson_kcycle(L, C.c_double(mass), n_refine, coarse_dof, _p(gauge), ptrs, _p(b), C.c_double(tol), max_iter, restart,
+                                C.c_double(inner_tol), C.c_double(coarsest_tol), n_smooth, _p(x), C.byref(true_res), ops, its)
+    return it, x, true_res.value, list(ops), list(its)

@@ -1,0 +1,69 @@
+"""GPU K-cycle parity: the C++ facade's StatefulMultigridMG::mg_preconditioner + Krylov drivers (product path,
+quantum-mg_amd/drivers/n13_wilson_kcycle, every step a HIP kernel through the C-ABI) against the CPU oracle's
+K-cycle on the SAME hierarchy: the driver dumps its null vectors and right-hand side, the oracle rebuilds the
+transfer operators and Galerkin coarse operators from them and solves the same system.
+
+Bar: true residual <= the requested 1e-10; outer iteration count equal to the oracle's +-1
+(bit-different reductions can move a restart); solutions agree to the solve tolerance.
+Also runs the n02 counterpart (known answers 4.01 / -1 / 20.0801 / -8.02 / 1 through the facade)."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import coordspace as cs
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVERS = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "quantum-mg_amd"), "-j4", "libqmg_hip.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", DRIVERS, "-j4"], stdout=subprocess.DEVNULL)
+
+
+def test_n02_free_laplace_driver_known_answers():
+    out = subprocess.run([os.path.join(DRIVERS, "n02_free_laplace")], cwd=DRIVERS, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    selfs = re.findall(r"Self: \(([-\d.e+]+),", out.stdout)
+    assert [float(s) for s in selfs] == pytest.approx([4.01, 4.01, 20.0801], abs=1e-12)
+    assert "Algorithm CG took" in out.stdout and "[QMG-ERROR]" not in out.stdout
+
+
+@pytest.mark.parametrize("L,n_refine,coarse_dof,mass", [(64, 1, 8, -0.07), (64, 2, 8, -0.07), (32, 1, 4, -0.03)])
+def test_wilson_kcycle_matches_oracle(golden_dir, L, n_refine, coarse_dof, mass):
+    gauge_file = os.path.join(golden_dir, "l%dt%db60_heatbath.dat" % (L, L))
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, QMG_QUIET="1", QMG_DUMP_DIR=tmp)
+        out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle"), str(L), str(mass), "6.0", str(n_refine), str(coarse_dof), gauge_file, str(L)],
+                             cwd=DRIVERS, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+        gpu_iters = int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1))
+        gpu_res = float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
+        nullvecs = [np.fromfile(os.path.join(tmp, "nullvecs_level%d.bin" % l), dtype=np.complex128) for l in range(n_refine)]
+        b = np.fromfile(os.path.join(tmp, "b.bin"), dtype=np.complex128)
+        x_gpu = np.fromfile(os.path.join(tmp, "x.bin"), dtype=np.complex128)
+    assert gpu_res <= 1e-10
+    ph = np.loadtxt(gauge_file)
+    gauge = ol.phases_to_gauge_u1(ph, L, L)
+    it, x_cpu, true_res, ops, its = ol.wilson_kcycle(L, mass, n_refine, coarse_dof, gauge, nullvecs, b)
+    assert it > 0 and true_res <= 1e-10
+    assert abs(gpu_iters - it) <= 1, (gpu_iters, it)
+    # both solve A x = b to 1e-10: the solutions agree to cond(A) * 1e-10
+    assert cs.rel_l2(x_gpu, x_cpu) < 1e-7
+    # the GPU solution satisfies the ORACLE's operator
+    clover, hopping = ol.wilson_fill(gauge, L, L)
+    d = ol.make_desc(L, L, 2, clover, hopping, mass)
+    assert cs.rel_l2(ol.stencil_apply(d, x_gpu), b) <= 1.1e-10
+    # Dslash counts per level as tracked by the facade (stateful_multigrid.h:854-865) vs the oracle's operator counts:
+    # level 0 = (n_pre + 1 + 1) + (1 + n_post + 1) applies per outer iteration in both
+    m = re.search(r"Level 0 NullVec 0 PreSmooth (\d+) Krylov 0 PostSmooth (\d+)", out.stdout)
+    assert int(m.group(1)) == 4 * gpu_iters and int(m.group(2)) == 3 * gpu_iters
