@@ -181,6 +181,17 @@ int qmg_coarse_build(void* coarse_clover, void* coarse_hopping, const qmg_stenci
                      const void* nullvecs, const void* restrict_vecs /* or NULL */,
                      int cLx, int cLy, int cnc, void* stream);
 
+/* ---------------- multi-GPU: independent right-hand sides per rank ---------------- */
+/* The path shards over right-hand sides; every rank holds a replica of the stencil/transfer data and
+ * there is no halo exchange.  The one collective is a sum all-reduce (RCCL over xGMI) of a small
+ * vector of per-RHS reduction results, once per Krylov reduction step, so all ranks take the same
+ * convergence decision.  Rank 0 creates the 128-byte id and ships it by any host channel. */
+int qmg_comm_get_unique_id(void* id128);
+int qmg_comm_init(const void* id128, int world, int rank);      /* collective; after qmg_init(local_rank) */
+int qmg_comm_world(int* world, int* rank);
+int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream);   /* in place, async; no-op when world == 1 */
+int qmg_comm_finalize(void);
+
 /* ---------------- tuning hooks (not part of the reference surface) ---------------- */
 /* key "stencil_nt": 1 = non-temporal loads for the stencil matrices in the nc<=4 kernel. */
 int qmg_set_tuning(const char* key, int value);

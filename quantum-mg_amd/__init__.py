@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
+    "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
 ]
 
 

@@ -1,0 +1,35 @@
+"""N>1 path on CPU: two gloo ranks (torch.distributed.run, 127.0.0.1) run tests/dist_worker.py."""
+import importlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sharding = importlib.import_module("quantum-mg_amd.sharding")
+
+
+def test_shard_rhs_partitions():
+    for total in (0, 1, 5, 8, 64):
+        for world in (1, 2, 3, 8):
+            seen = []
+            sizes = []
+            for r in range(world):
+                idx = sharding.shard_rhs(total, r, world)
+                seen += idx
+                sizes.append(len(idx))
+            assert seen == list(range(total))
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_rhs(64, 3, 8) == list(range(24, 32))      # BASELINE configs[3]: 64 RHS over 8 GPUs
+    with pytest.raises(ValueError):
+        sharding.shard_rhs(4, 2, 2)
+
+
+def test_two_rank_gloo_worker():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tests", "dist_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
