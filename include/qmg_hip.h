@@ -143,6 +143,8 @@ int qmg_cxpay(const void* x, double ar, double ai, void* y, size_t n, void* stre
 int qmg_caxpby(double ar, double ai, const void* x, double br, double bi, void* y, size_t n, void* stream);            /* y = a x + b y */
 int qmg_cxpyz(const void* x, const void* y, void* z, size_t n, void* stream);                         /* z  = x + y        */
 int qmg_caxpbyz(double ar, double ai, const void* x, double br, double bi, const void* y, void* z, size_t n, void* stream); /* z = a x + b y */
+/* y += sum_{i<k} a_i x_i in one pass. coeffs: HOST array of 2k doubles (re,im); xs: HOST array of k device pointers. */
+int qmg_multi_caxpy(const double* coeffs, const void* const* xs, int k, void* y, size_t n, void* stream);
 /* y[site,c] = scale[c] * x[site,shuffle[c]]  (caxy_shuffle_pattern; gamma5 / sigma1 / chiral projections,
  * wilson.h:74-143, coarse.h:498-657).  nc <= 64; scale/shuffle are HOST arrays of length nc. */
 int qmg_caxy_pattern(const double* scale, const int* shuffle, int nc, const void* x, void* y, size_t nsite, void* stream);

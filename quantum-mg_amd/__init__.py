@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "qmg_cshift", "qmg_stencil_apply", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
     "qmg_build_dagger", "qmg_build_rbjacobi", "qmg_cmat_conjtrans",
     "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",
-    "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_caxy_pattern", "qmg_gaussian",
+    "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
@@ -242,6 +242,13 @@ def cxpyz(x, y, z, n):
 
 def caxpbyz(a, x, b, y, z, n):
     check(lib().qmg_caxpbyz(*_scalar(a), _vp(x), *_scalar(b), _vp(y), _vp(z), C.c_size_t(n), None))
+
+
+def multi_caxpy(coeffs, xs, y, n):
+    k = len(xs)
+    cf = (C.c_double * (2 * k))(*[v for a in coeffs for v in (complex(a).real, complex(a).imag)])
+    ptrs = (C.c_void_p * k)(*[(x.ptr if isinstance(x, DeviceArray) else int(x)) for x in xs])
+    check(lib().qmg_multi_caxpy(cf, ptrs, k, _vp(y), C.c_size_t(n), None), "qmg_multi_caxpy")
 
 
 def caxy_pattern(scale, shuffle, x, y, nsite):

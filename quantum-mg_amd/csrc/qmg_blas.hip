@@ -39,6 +39,17 @@ __global__ __launch_bounds__(BLOCK) void k_blas(cplx* __restrict__ z, const cplx
   }
 }
 
+// y += sum_i a_i x_i for up to 32 vectors in ONE pass (GCR orthogonalisation: 2k separate caxpy launches -> 2)
+constexpr int MAXPY_K = 32;
+struct MultiAxpy { const cplx* x[MAXPY_K]; cplx a[MAXPY_K]; };
+__global__ __launch_bounds__(BLOCK) void k_multi_caxpy(cplx* __restrict__ y, MultiAxpy m, int k, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    cplx acc = y[i];
+    for (int j = 0; j < k; j++) cmac(acc, m.a[j], m.x[j][i]);
+    y[i] = acc;
+  }
+}
+
 struct Pattern { double scale[64]; int shuffle[64]; };
 __global__ __launch_bounds__(BLOCK) void k_pattern(cplx* __restrict__ y, const cplx* __restrict__ x, long nsite, int nc, Pattern pat) {
   const long n = nsite * nc;
@@ -289,6 +300,25 @@ int qmg_cxpyz(const void* x, const void* y, void* z, size_t n, void* s) {
 int qmg_caxpbyz(double ar, double ai, const void* x, double br, double bi, const void* y, void* z, size_t n, void* s) {
   if ((!x || !y || !z) && n) return QMG_ERR_INVALID;
   return blas_launch<OP_CAXPBYZ>(z, x, y, make_double2(ar, ai), make_double2(br, bi), n, s);
+}
+
+int qmg_multi_caxpy(const double* coeffs, const void* const* xs, int k, void* y, size_t n, void* s) {
+  if (k < 0 || (k > 0 && (!coeffs || !xs)) || (!y && n)) return QMG_ERR_INVALID;
+  if (n == 0) return QMG_SUCCESS;
+  int done = 0;
+  while (done < k) {
+    const int kk = (k - done > MAXPY_K) ? MAXPY_K : k - done;
+    MultiAxpy m;
+    for (int j = 0; j < kk; j++) {
+      if (!xs[done + j]) return QMG_ERR_INVALID;
+      m.x[j] = (const cplx*)xs[done + j];
+      m.a[j] = make_double2(coeffs[2 * (done + j)], coeffs[2 * (done + j) + 1]);
+    }
+    k_multi_caxpy<<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)y, m, kk, (long)n);
+    QMG_LAUNCH_CHECK();
+    done += kk;
+  }
+  return QMG_SUCCESS;
 }
 
 int qmg_caxy_pattern(const double* scale, const int* shuffle, int nc, const void* x, void* y, size_t nsite, void* s) {

@@ -67,6 +67,15 @@ inline std::vector<complex<double>> multidot(const std::vector<complex<double>*>
   return out;
 }
 
+// y += sum_i a_i x_i, i < k, in one pass (qmg_multi_caxpy)
+inline void multi_caxpy(const std::vector<complex<double>>& a, const std::vector<complex<double>*>& xs, int k, complex<double>* y, size_t n) {
+  if (k <= 0) return;
+  std::vector<double> cf(2 * k);
+  std::vector<const void*> ptrs(k);
+  for (int i = 0; i < k; i++) { cf[2 * i] = a[i].real(); cf[2 * i + 1] = a[i].imag(); ptrs[i] = xs[i]; }
+  ok(qmg_multi_caxpy(cf.data(), ptrs.data(), k, y, n, current_stream()), "qmg_multi_caxpy");
+}
+
 }  // namespace qmg
 
 // ---------------------------------------------------------------------------------------------
@@ -87,17 +96,24 @@ inline inversion_info minv_vector_minres(complex<double>* phi, complex<double>* 
   matrix_vector(p, phi, extra_info); ops++;
   caxpbyz(1.0, phi0, -1.0, p, r, size);
   double rsq = norm2sq(r, size);
+  double rsq_ref = rsq;
   int k = 0;
   bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
   while (!conv && k < max_iter) {
     matrix_vector(p, r, extra_info); ops++;
-    const complex<double> pr = dot(p, r, size);
-    const double pp = norm2sq(p, size);
+    // <r,p> and <p,p> in one pass over p; the new residual norm follows analytically:
+    // |r - a p|^2 = |r|^2 - (2 omega - omega^2) |<p,r>|^2 / <p,p>   for a = omega <p,r>/<p,p>
+    std::vector<complex<double>*> rp = {r, p};
+    std::vector<complex<double>> d2 = qmg::multidot(rp, 2, p, size);
+    const complex<double> pr = std::conj(d2[0]);
+    const double pp = d2[1].real();
     if (pp == 0.0) break;
     const complex<double> alpha = omega * pr / pp;
     caxpy(alpha, r, phi, size);
     caxpy(-alpha, p, r, size);
-    rsq = norm2sq(r, size);
+    // (the subtraction loses absolute accuracy ~1e-16 * rsq_ref: re-anchor with a true norm after every 8 orders of magnitude)
+    rsq = rsq - (2.0 * omega - omega * omega) * std::norm(pr) / pp;
+    if (!(rsq > 1e-8 * rsq_ref) || std::sqrt(rsq) < 4.0 * eps * bnorm) { rsq = norm2sq(r, size); rsq_ref = rsq; }
     k++;
     qmg::report(verb, "MinRes", k, std::sqrt(rsq) / bnorm);
     if (std::sqrt(rsq) < eps * bnorm) conv = true;
@@ -186,6 +202,7 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
   matrix_vector(tmp, phi, extra_info); ops++;
   caxpbyz(1.0, phi0, -1.0, tmp, r, size);
   double rsq = norm2sq(r, size);
+  double rsq_ref = rsq;
   bool conv = (bnorm == 0.0) || (std::sqrt(rsq) < eps * bnorm);
   int k = 0, kb = 0;   // total iterations, index within the current basis
   inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
@@ -197,21 +214,26 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
     if (precond) { zero_vector(z, size); precond(z, r, size, precond_info, &pverb); }
     else copy_vector(z, r, size);
     matrix_vector(w, z, extra_info); ops++;
-    if (kb > 0) {   // modified-in-one-pass Gram-Schmidt against the current basis
+    if (kb > 0) {   // Gram-Schmidt against the current basis: ONE multi-dot pass, then TWO fused multi-axpy passes
       std::vector<complex<double>> c = qmg::multidot(W, kb, w, size);
-      for (int i = 0; i < kb; i++) {
-        const complex<double> beta = c[i] / Wnorm2[i];
-        caxpy(-beta, W[i], w, size);
-        caxpy(-beta, Z[i], z, size);
-      }
+      for (int i = 0; i < kb; i++) c[i] = -c[i] / Wnorm2[i];
+      qmg::multi_caxpy(c, W, kb, w, size);
+      qmg::multi_caxpy(c, Z, kb, z, size);
     }
-    const double ww = norm2sq(w, size);
+    // <r,w> and <w,w> in one pass over w
+    std::vector<complex<double>*> rw = {r, w};
+    std::vector<complex<double>> d2 = qmg::multidot(rw, 2, w, size);
+    const double ww = d2[1].real();
     if (ww == 0.0) break;
     Wnorm2[kb] = ww;
-    const complex<double> alpha = dot(w, r, size) / ww;
+    const complex<double> wr = std::conj(d2[0]);   // <w,r>
+    const complex<double> alpha = wr / ww;
     caxpy(alpha, z, phi, size);
     caxpy(-alpha, w, r, size);
-    rsq = norm2sq(r, size);
+    // |r - alpha w|^2 = |r|^2 - |<w,r>|^2 / <w,w>: no extra reduction; confirmed by a true norm near convergence
+    // (the subtraction loses absolute accuracy ~1e-16 * rsq_ref: re-anchor with a true norm after every 8 orders of magnitude)
+    rsq = rsq - std::norm(wr) / ww;
+    if (!(rsq > 1e-8 * rsq_ref) || std::sqrt(rsq) < 4.0 * eps * bnorm) { rsq = norm2sq(r, size); rsq_ref = rsq; }
     k++; kb++;
     qmg::report(verb, name, k, std::sqrt(rsq) / bnorm);
     if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
@@ -219,6 +241,7 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
       matrix_vector(tmp, phi, extra_info); ops++;
       caxpbyz(1.0, phi0, -1.0, tmp, r, size);
       rsq = norm2sq(r, size);
+      rsq_ref = rsq;
       kb = 0;
       if (verb && verb->verbosity >= VERB_RESTART_DETAIL) std::cout << verb->verb_prefix << name << " restart at iter " << k << " RelTol " << std::sqrt(rsq) / bnorm << "\n";
       if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }

@@ -325,6 +325,18 @@ def test_multidot(k):
     assert np.max(np.abs(got - want)) <= RTOL_RED * n
 
 
+@pytest.mark.parametrize("k", [1, 5, 32, 40])
+def test_multi_caxpy(k):
+    n = 30011
+    xs = [cs.gaussian_cvec(n, 10 + i) for i in range(k)]
+    a = cs.gaussian_cvec(k, 77)
+    y = cs.gaussian_cvec(n, 99)
+    dy = D(y)
+    qmg.multi_caxpy(list(a), [D(x) for x in xs], dy, n)
+    want = y + sum(ai * xi for ai, xi in zip(a, xs))
+    assert cs.rel_l2(dy.to_host(), want) < 1e-14
+
+
 def test_timeslice_reductions():
     Lx, Ly, nc = 16, 12, 2
     a, b = cs.gaussian_cvec(Lx * Ly * nc, 1), cs.gaussian_cvec(Lx * Ly * nc, 2)
