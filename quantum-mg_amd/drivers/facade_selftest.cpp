@@ -1,0 +1,192 @@
+// facade_selftest -- device-side checks of the C++ facade against the identities the reference's own
+// tests print (they store no numbers): every check recomputes a quantity two ways on the GPU
+// through the facade's reference-named methods and compares.  Exit code = number of failed checks.
+//   n00  cshift round trip                                   (tests/n00_cshift)
+//   n04  staggered even-odd preconditioned solve             (tests/n04_staggered_test, staggered.h:190-240)
+//   n03  gauged Laplace even-odd preconditioned solve        (tests/n03_gauge_laplace_test, gaugedlaplace.h:154-204)
+//   n08  Galerkin: built coarse op == emulated R A P         (tests/n08_distance1_build_test:117-147, multigrid.h:465-512)
+//   n17  <y, M x> = <M^dag y, x>, M^dag M / M M^dag          (tests/n17_dagger_stencil_test:85-96)
+//   n18  right-block-Jacobi and Schur solves reconstruct the ORIGINAL system   (tests/n18_rbjacobi_stencil_test:153-231)
+//   n21  rbj-dagger normal equations (CGNE / CGNR)           (tests/n21_rbj_dagger_stencil_test:138-209)
+//   storage / lattice / multigrid bookkeeping
+#include <cmath>
+#include <iostream>
+#include <string>
+
+#include "../include/qmg/qmg.hpp"
+
+using namespace std;
+
+static int failures = 0;
+static void check(bool okv, const string& what, double val) {
+  cout << (okv ? "[ OK ] " : "[FAIL] ") << what << " : " << val << "\n";
+  if (!okv) failures++;
+}
+static double rel_resid(Stencil2D* op, complex<double>* x, complex<double>* b, long n) {   // ||b - A x|| / ||b|| with the ORIGINAL operator
+  complex<double>* Ax = allocate_vector<complex<double>>(n);
+  zero_vector(Ax, n);
+  op->apply_M(Ax, x);
+  const double r = sqrt(diffnorm2sq(b, Ax, n) / norm2sq(b, n));
+  deallocate_vector(&Ax);
+  return r;
+}
+
+int main(int argc, char** argv) {
+  const string gauge_file = (argc > 1) ? argv[1] : "../../tests/golden/l32t32b60_heatbath.dat";
+  if (!qmg::ok(qmg_init(0), "qmg_init")) return 100;
+  const int L = 32;
+  Lattice2D lat1(L, L, 1), lat2(L, L, 2);
+  complex<double>* gauge = allocate_vector<complex<double>>(lat1.get_size_gauge());
+  if (!read_gauge_u1(gauge, &lat1, gauge_file)) return 101;
+  const long n1 = lat1.get_size_cv_l(), n2 = lat2.get_size_cv_l();
+  inversion_verbose_struct quiet(VERB_NONE, "");
+
+  // ---- lattice / storage bookkeeping
+  {
+    int bad = 0;
+    for (int x = 0; x < L; x++) for (int y = 0; y < L; y++) { int xx, yy; lat2.index_to_coord(lat2.coord_to_index(x, y), xx, yy); if (xx != x || yy != y) bad++; }
+    check(bad == 0, "Lattice2D coord<->index round trip", bad);
+    ArrayStorageMG<complex<double>> pool(n1, 2);
+    complex<double>*a = pool.check_out(), *b = pool.check_out(), *c = pool.check_out();
+    bool okp = pool.get_number_allocated() == 3 && pool.get_number_checked() == 3 && a != b && b != c;
+    pool.check_in(b); pool.check_in(c);
+    okp = okp && pool.get_number_checked() == 1 && pool.check_out() == b;
+    pool.check_in(b); pool.check_in(a);
+    pool.consolidate(1);
+    check(okp && pool.get_number_allocated() >= 1 && pool.get_number_checked() == 0, "ArrayStorageMG check_out/check_in/consolidate", pool.get_number_allocated());
+  }
+
+  // ---- n00: cshift there and back is the identity
+  {
+    complex<double>*v = allocate_vector<complex<double>>(n2), *s = allocate_vector<complex<double>>(n2), *t = allocate_vector<complex<double>>(n2);
+    gaussian(v, n2, 5);
+    cshift(s, v, QMG_CSHIFT_FROM_XP1, QMG_EO_FROM_EVENODD, 2, &lat2);
+    cshift(t, s, QMG_CSHIFT_FROM_XM1, QMG_EO_FROM_EVENODD, 2, &lat2);
+    double d = diffnorm2sq(t, v, n2);
+    cshift(s, v, QMG_CSHIFT_FROM_YM1, QMG_EO_FROM_EVENODD, 2, &lat2);
+    cshift(t, s, QMG_CSHIFT_FROM_YP1, QMG_EO_FROM_EVENODD, 2, &lat2);
+    d += diffnorm2sq(t, v, n2);
+    check(d == 0.0, "n00 cshift round trips", d);
+    deallocate_vector(&v); deallocate_vector(&s); deallocate_vector(&t);
+  }
+
+  // ---- n04 / n03: even-odd preconditioned CG for staggered and gauged Laplace
+  {
+    Staggered2D stag(&lat1, 0.1, gauge);
+    complex<double>*b = allocate_vector<complex<double>>(n1), *bp = allocate_vector<complex<double>>(n1), *x = allocate_vector<complex<double>>(n1);
+    gaussian(b, n1, 11);
+    zero_vector(bp, n1); zero_vector(x, n1);
+    stag.prepare_b(bp, b);
+    inversion_info inv = minv_vector_cg(x, bp, (int)(n1 / 2), 4000, 1e-10, apply_eo_staggered_2D_M, (void*)&stag, &quiet);
+    stag.reconstruct_x(x, b);
+    check(inv.success && rel_resid(&stag, x, b, n1) < 1e-8, "n04 staggered eo-preconditioned CG solves the full system", rel_resid(&stag, x, b, n1));
+    GaugedLaplace2D lap(&lat1, 0.01, gauge);
+    zero_vector(bp, n1); zero_vector(x, n1);
+    lap.prepare_b(bp, b);
+    inv = minv_vector_cg(x, bp, (int)(n1 / 2), 4000, 1e-10, apply_eo_gauge_laplace_2D_M, (void*)&lap, &quiet);
+    lap.reconstruct_x(x, b);
+    check(inv.success && rel_resid(&lap, x, b, n1) < 1e-8, "n03 gauged-Laplace eo-preconditioned CG solves the full system", rel_resid(&lap, x, b, n1));
+    deallocate_vector(&b); deallocate_vector(&bp); deallocate_vector(&x);
+  }
+
+  // ---- Wilson: dagger, normal equations, rbjacobi, Schur, rbj-dagger
+  Wilson2D wilson(&lat2, complex<double>(0.05, 0.0), gauge);
+  {
+    complex<double>*x = allocate_vector<complex<double>>(n2), *y = allocate_vector<complex<double>>(n2), *t = allocate_vector<complex<double>>(n2),
+                   *u = allocate_vector<complex<double>>(n2), *b = allocate_vector<complex<double>>(n2), *bp = allocate_vector<complex<double>>(n2);
+    gaussian(x, n2, 21); gaussian(y, n2, 22); gaussian(b, n2, 23);
+    wilson.build_dagger_stencil();
+    zero_vector(t, n2); wilson.apply_M(t, x);
+    zero_vector(u, n2); wilson.apply_M_dagger(u, y);
+    const complex<double> lhs = dot(y, t, n2), rhs = dot(u, x, n2);
+    check(abs(lhs - rhs) / abs(lhs) < 1e-12, "n17 <y, M x> = <M^dag y, x>", abs(lhs - rhs) / abs(lhs));
+    // gamma5-hermiticity: M^dag = g5 M g5
+    wilson.gamma5(t, y); zero_vector(bp, n2); wilson.apply_M(bp, t); wilson.gamma5(bp);
+    check(sqrt(diffnorm2sq(bp, u, n2) / norm2sq(u, n2)) < 1e-13, "Wilson gamma5-hermiticity M^dag = g5 M g5", sqrt(diffnorm2sq(bp, u, n2) / norm2sq(u, n2)));
+    // CGNR: M^dag M x = M^dag b through the type dispatch (prepare / apply function / reconstruct)
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_MDAGGER_M);
+    zero_vector(t, n2);
+    inversion_info inv = minv_vector_cg(t, bp, (int)n2, 4000, 1e-11, Stencil2D::get_apply_function(QMG_MATVEC_MDAGGER_M), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_MDAGGER_M);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n17 CGNR (M^dag M) solves the original system", rel_resid(&wilson, u, b, n2));
+    // CGNE: M M^dag y = b, x = M^dag y
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_M_MDAGGER);
+    zero_vector(t, n2);
+    inv = minv_vector_cg(t, bp, (int)n2, 4000, 1e-11, Stencil2D::get_apply_function(QMG_MATVEC_M_MDAGGER), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_M_MDAGGER);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n17 CGNE (M M^dag) solves the original system", rel_resid(&wilson, u, b, n2));
+
+    // n18: right block Jacobi  (A C^-1) y = b, x = C^-1 y
+    wilson.build_rbjacobi_stencil();
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_RIGHT_JACOBI);
+    zero_vector(t, n2);
+    inv = minv_vector_gcr_restart(t, bp, (int)n2, 4000, 1e-10, 32, Stencil2D::get_apply_function(QMG_MATVEC_RIGHT_JACOBI), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_RIGHT_JACOBI);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n18 right-block-Jacobi GCR reconstructs the original solution", rel_resid(&wilson, u, b, n2));
+    // n18/n19: Schur system on the even half
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_RIGHT_SCHUR);
+    zero_vector(t, n2);
+    inv = minv_vector_gcr_restart(t, bp, (int)(n2 / 2), 4000, 1e-10, 32, Stencil2D::get_apply_function(QMG_MATVEC_RIGHT_SCHUR), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_RIGHT_SCHUR);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n18 Schur (even-odd) GCR reconstructs the original solution", rel_resid(&wilson, u, b, n2));
+    const int schur_iters = inv.iter;
+    // rbjacobi apply == original apply composed with cinv
+    zero_vector(t, n2); wilson.apply_M_rbjacobi_cinv(t, x);
+    zero_vector(u, n2); wilson.apply_M(u, t);
+    zero_vector(bp, n2); wilson.apply_M_rbjacobi(bp, x);
+    check(sqrt(diffnorm2sq(bp, u, n2) / norm2sq(u, n2)) < 1e-12, "rbjacobi apply == M . C^-1", sqrt(diffnorm2sq(bp, u, n2) / norm2sq(u, n2)));
+
+    // n21: rbj-dagger and the two right-Jacobi normal operators
+    wilson.build_rbj_dagger_stencil();
+    zero_vector(t, n2); wilson.apply_M_rbjacobi(t, x);
+    zero_vector(u, n2); wilson.apply_M_rbj_dagger(u, y);
+    const complex<double> l2 = dot(y, t, n2), r2 = dot(u, x, n2);
+    check(abs(l2 - r2) / abs(l2) < 1e-12, "n21 <y, M_rbj x> = <M_rbj^dag y, x>", abs(l2 - r2) / abs(l2));
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_RBJ_MDAGGER_M);
+    zero_vector(t, n2);
+    inv = minv_vector_cg(t, bp, (int)n2, 4000, 1e-11, Stencil2D::get_apply_function(QMG_MATVEC_RBJ_MDAGGER_M), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_RBJ_MDAGGER_M);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n21 rbj CGNR (M^dag M) reconstructs the original solution", rel_resid(&wilson, u, b, n2));
+    zero_vector(bp, n2); wilson.prepare_M(bp, b, QMG_MATVEC_RBJ_M_MDAGGER);
+    zero_vector(t, n2);
+    inv = minv_vector_cg(t, bp, (int)n2, 4000, 1e-11, Stencil2D::get_apply_function(QMG_MATVEC_RBJ_M_MDAGGER), (void*)&wilson, &quiet);
+    zero_vector(u, n2); wilson.reconstruct_M(u, t, b, QMG_MATVEC_RBJ_M_MDAGGER);
+    check(inv.success && rel_resid(&wilson, u, b, n2) < 1e-8, "n21 rbj CGNE (M M^dag) reconstructs the original solution", rel_resid(&wilson, u, b, n2));
+    cout << "       (Schur GCR iterations: " << schur_iters << ")\n";
+    for (complex<double>** p : {&x, &y, &t, &u, &b, &bp}) deallocate_vector(p);
+  }
+
+  // ---- n08: Galerkin through MultigridMG: built coarse stencil vs the emulated level (R A P)
+  {
+    const int nvec = 4;
+    Lattice2D clat(L / 4, L / 4, nvec);
+    complex<double>** nv = new complex<double>*[nvec];
+    for (int j = 0; j < nvec; j++) { nv[j] = allocate_vector<complex<double>>(n2); gaussian(nv[j], n2, 40 + j); }
+    TransferMG transfer(&lat2, &clat, nv, true, false, QMG_DOUBLE_NONE);
+    // P^dag P = 1 (n05)
+    const long nc_ = clat.get_size_cv_l();
+    complex<double>*vc = allocate_vector<complex<double>>(nc_), *vf = allocate_vector<complex<double>>(n2), *vc2 = allocate_vector<complex<double>>(nc_);
+    gaussian(vc, nc_, 50); zero_vector(vf, n2); zero_vector(vc2, nc_);
+    transfer.prolong_c2f(vc, vf); transfer.restrict_f2c(vf, vc2);
+    check(sqrt(diffnorm2sq(vc, vc2, nc_) / norm2sq(vc, nc_)) < 1e-13, "n05 P^dag P = 1 on the coarse space", sqrt(diffnorm2sq(vc, vc2, nc_) / norm2sq(vc, nc_)));
+    MultigridMG built(&lat2, &wilson), emulated(&lat2, &wilson);
+    built.push_level(&clat, &transfer, true, false, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL, nv);
+    emulated.push_level(&clat, &transfer, false, false, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL, (complex<double>**)0);
+    complex<double>*o1 = allocate_vector<complex<double>>(nc_), *o2 = allocate_vector<complex<double>>(nc_);
+    zero_vector(o1, nc_); zero_vector(o2, nc_);
+    built.apply_stencil(o1, vc, 1);
+    emulated.apply_stencil(o2, vc, 1);
+    check(sqrt(diffnorm2sq(o1, o2, nc_) / norm2sq(o2, nc_)) < 1e-12, "n08 Galerkin: built coarse apply == emulated R A P", sqrt(diffnorm2sq(o1, o2, nc_) / norm2sq(o2, nc_)));
+    check(built.get_num_levels() == 2 && built.get_global_null_vectors(0) != 0 && emulated.get_stencil(1) == 0, "MultigridMG level bookkeeping", built.get_num_levels());
+    built.pop_level();
+    check(built.get_num_levels() == 1, "MultigridMG pop_level", built.get_num_levels());
+    for (complex<double>** p : {&vc, &vf, &vc2, &o1, &o2}) deallocate_vector(p);
+    for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
+    delete[] nv;
+  }
+
+  deallocate_vector(&gauge);
+  qmg::VecPool::release_all();
+  cout << (failures ? "[SELFTEST FAILED] " : "[SELFTEST PASSED] ") << failures << " failure(s)\n";
+  return failures;
+}

@@ -37,6 +37,15 @@ def test_n02_free_laplace_driver_known_answers():
     assert "Algorithm CG took" in out.stdout and "[QMG-ERROR]" not in out.stdout
 
 
+def test_facade_selftest_reference_identities(golden_dir):
+    """n00 / n03 / n04 / n05 / n08 / n17 / n18 / n21 identities and solves through the C++ facade on the GPU."""
+    out = subprocess.run([os.path.join(DRIVERS, "facade_selftest"), os.path.join(golden_dir, "l32t32b60_heatbath.dat")], cwd=DRIVERS,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "[SELFTEST PASSED]" in out.stdout, out.stdout[-4000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+    assert out.stdout.count("[ OK ]") >= 18
+
+
 @pytest.mark.parametrize("L,n_refine,coarse_dof,mass", [(64, 1, 8, -0.07), (64, 2, 8, -0.07), (32, 1, 4, -0.03)])
 def test_wilson_kcycle_matches_oracle(golden_dir, L, n_refine, coarse_dof, mass):
     gauge_file = os.path.join(golden_dir, "l%dt%db60_heatbath.dat" % (L, L))
