@@ -1,0 +1,157 @@
+// n19_wilson_kcycle_precond -- the build's counterpart of
+// tests/n19_wilson_kcycle_precond/wilson_kcycle_precond.cpp on the GPU: a Wilson K-cycle in which EVERY level
+// is solved as the even-odd Schur complement of its right-block-Jacobi preconditioned operator
+// (solve_type = QMG_MATVEC_RIGHT_SCHUR, n19:107), the coarse operators are Galerkin-coarsened from the
+// rbjacobi stencil (n19:171, coarse.h:120-123) and get their own rbjacobi variant
+// (QMG_COARSE_BUILD_RBJACOBI, n19:290).
+//   ./n19_wilson_kcycle_precond [L=128] [n_refine=3] [gauge_file] [tile]
+// Constants as n19:50-107: mass -0.07, 4x4 blocks, coarse_dof 8, outer tol 1e-8 / 1000 / restart 32,
+// inner and coarsest 0.2 / 1000 / 32, 2+2 MR smoothing; null vectors: 4 gaussian vectors relaxed on the
+// rbjacobi residual equation by GCR(64), 500 its, 5e-5 (n19:222), chirally doubled.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "../include/qmg/qmg.hpp"
+
+using namespace std;
+
+int main(int argc, char** argv) {
+  cout << setprecision(20);
+  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  const int x_len = (argc > 1) ? stoi(argv[1]) : 128, y_len = x_len;
+  const int n_refine = (argc > 2) ? stoi(argv[2]) : 3;
+  const string gauge_file = (argc > 3) ? argv[3] : "../../tests/golden/l128t128b60_heatbath.dat";
+  const int tile = (argc > 4) ? stoi(argv[4]) : x_len;
+  const bool quiet = getenv("QMG_QUIET") != 0;
+  const int dof = Wilson2D::get_dof();
+  const double mass = -0.07;
+  const int x_block = 4, y_block = 4, coarse_dof = 8;
+  const double tol = 1e-8; const int max_iter = 1000; const int restart_freq = 32;
+  const double inner_tol = 0.2; const int inner_max_iter = 1000; const int inner_restart_freq = 32;
+  const int n_pre_smooth = 2; const double pre_smooth_tol = 1e-15;
+  const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
+  const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
+  const QMGStencilType solve_type = QMG_MATVEC_RIGHT_SCHUR;
+  unsigned long long seed = 1337ull;
+
+  inversion_info invif;
+  inversion_verbose_struct verb;
+  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verb_prefix = "Level 0: ";
+  verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.precond_verb_prefix = "Prec ";
+  inversion_verbose_struct verb_null(VERB_NONE, "");
+
+  Lattice2D** lats = new Lattice2D*[n_refine + 1];
+  lats[0] = new Lattice2D(x_len, y_len, dof);
+  Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
+  complex<double>* gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
+  bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
+  if (!got) return 3;
+  delete lat_gauge;
+
+  Wilson2D* wilson_op = new Wilson2D(lats[0], mass, gauge_field);
+  wilson_op->build_rbjacobi_stencil();   // n19:155
+
+  StatefulMultigridMG::LevelSolveMG** level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
+  StatefulMultigridMG::CoarsestSolveMG* coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
+  coarsest_solve_obj->coarsest_stencil_app = solve_type;
+  coarsest_solve_obj->coarsest_tol = coarsest_tol;
+  coarsest_solve_obj->coarsest_iters = coarsest_max_iter;
+  coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
+  StatefulMultigridMG* mg_object = new StatefulMultigridMG(lats[0], wilson_op, coarsest_solve_obj);
+  const MultigridMG::QMGMultigridPrecondStencil stencil_to_coarsen = MultigridMG::QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI;
+
+  int curr_x_len = x_len, curr_y_len = y_len;
+  TransferMG** transfer_objs = new TransferMG*[n_refine];
+  for (int i = 1; i <= n_refine; i++) {
+    curr_x_len /= x_block; curr_y_len /= y_block;
+    lats[i] = new Lattice2D(curr_x_len, curr_y_len, coarse_dof);
+    const long fsize = lats[i - 1]->get_size_cv_l();
+    complex<double>** null_vectors = new complex<double>*[coarse_dof];
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      null_vectors[j] = allocate_vector<complex<double>>(fsize);
+      zero_vector(null_vectors[j], fsize);
+      complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
+      gaussian(rand_guess, fsize, seed++);
+      for (int k = 0; k < j; k++) orthogonal(rand_guess, null_vectors[k], fsize);
+      complex<double>* Arand_guess = mg_object->get_storage(i - 1)->check_out();
+      zero_vector(Arand_guess, fsize);
+      mg_object->get_stencil(i - 1)->apply_M(Arand_guess, rand_guess, QMG_MATVEC_RIGHT_JACOBI);
+      cax(-1.0, Arand_guess, fsize);
+      minv_vector_gcr_restart(null_vectors[j], Arand_guess, (int)fsize, 500, 5e-5, 64, apply_stencil_2D_M_rbjacobi, (void*)mg_object->get_stencil(i - 1), &verb_null);
+      cxpy(rand_guess, null_vectors[j], fsize);
+      mg_object->get_storage(i - 1)->check_in(rand_guess);
+      mg_object->get_storage(i - 1)->check_in(Arand_guess);
+      for (int k = 0; k < j; k++) orthogonal(null_vectors[j], null_vectors[k], fsize);
+    }
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      null_vectors[j + lats[i]->get_nc() / 2] = allocate_vector<complex<double>>(fsize);
+      mg_object->get_stencil(i - 1)->chiral_projection_both(null_vectors[j], null_vectors[j + lats[i]->get_nc() / 2]);
+      normalize(null_vectors[j], fsize);
+      normalize(null_vectors[j + lats[i]->get_nc() / 2], fsize);
+    }
+    transfer_objs[i - 1] = new TransferMG(lats[i - 1], lats[i], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
+    level_solve_objs[i - 1] = new StatefulMultigridMG::LevelSolveMG;
+    level_solve_objs[i - 1]->fine_stencil_app = solve_type;
+    level_solve_objs[i - 1]->intermediate_tol = inner_tol;
+    level_solve_objs[i - 1]->intermediate_iters = inner_max_iter;
+    level_solve_objs[i - 1]->intermediate_restart_freq = inner_restart_freq;
+    level_solve_objs[i - 1]->pre_tol = pre_smooth_tol;
+    level_solve_objs[i - 1]->pre_iters = n_pre_smooth;
+    level_solve_objs[i - 1]->post_tol = post_smooth_tol;
+    level_solve_objs[i - 1]->post_iters = n_post_smooth;
+    mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, Wilson2D::has_chirality() == QMG_CHIRAL_YES, stencil_to_coarsen,
+                          CoarseOperator2D::QMG_COARSE_BUILD_RBJACOBI, null_vectors);
+    for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
+    delete[] null_vectors;
+    cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built from the rbjacobi stencil\n";
+  }
+
+  matrix_op_cplx apply_stencil_op = Stencil2D::get_apply_function(solve_type);
+  const int solve_size = lats[0]->get_size_cv() / 2;
+
+  complex<double>* b = mg_object->check_out(0);
+  gaussian(b, lats[0]->get_size_cv_l(), seed++);
+  const double bnorm = sqrt(norm2sq(b, lats[0]->get_size_cv_l()));
+  complex<double>* x = mg_object->check_out(0);
+  zero_vector(x, lats[0]->get_size_cv_l());
+  complex<double>* Ax = mg_object->check_out(0);
+  zero_vector(Ax, lats[0]->get_size_cv_l());
+  complex<double>* b_prep = mg_object->check_out(0);
+  zero_vector(b_prep, lats[0]->get_size_cv_l());
+  mg_object->get_stencil(0)->prepare_M(b_prep, b, solve_type);
+
+  auto t0 = std::chrono::steady_clock::now();
+  invif = minv_vector_gcr_var_precond_restart(x, b_prep, solve_size, max_iter, tol, restart_freq, apply_stencil_op, (void*)mg_object->get_stencil(0),
+                                              StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
+  qmg_stream_sync(0);
+  const double solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  cout << "Multigrid " << (invif.success ? "converged" : "failed to converge") << " in " << invif.iter << " iterations with alleged tolerance "
+       << sqrt(invif.resSq) / bnorm << ".\n";
+
+  complex<double>* x_reconstruct = mg_object->check_out(0);
+  zero_vector(x_reconstruct, lats[0]->get_size_cv_l());
+  mg_object->get_stencil(0)->reconstruct_M(x_reconstruct, x, b, solve_type);
+  zero_vector(Ax, lats[0]->get_size_cv_l());
+  mg_object->apply_stencil(Ax, x_reconstruct, 0);   // the ORIGINAL operator
+  const double true_res = sqrt(diffnorm2sq(b, Ax, lats[0]->get_size_cv_l())) / bnorm;
+  cout << "Check tolerance " << true_res << "\n";
+  cout << setprecision(6) << "[QMG-TIMING]: solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
+  mg_object->check_in(b_prep, 0); mg_object->check_in(x_reconstruct, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
+
+  const bool ok_ = invif.success && true_res < 20 * tol;
+  delete mg_object;
+  for (int i = 0; i < n_refine; i++) { delete transfer_objs[i]; delete level_solve_objs[i]; }
+  delete[] transfer_objs; delete[] level_solve_objs; delete coarsest_solve_obj;
+  delete wilson_op;
+  for (int i = 0; i <= n_refine; i++) delete lats[i];
+  delete[] lats;
+  deallocate_vector(&gauge_field);
+  qmg::VecPool::release_all();
+  return ok_ ? 0 : 1;
+}

@@ -46,6 +46,21 @@ def test_facade_selftest_reference_identities(golden_dir):
     assert out.stdout.count("[ OK ]") >= 18
 
 
+@pytest.mark.parametrize("L,n_refine", [(128, 3), (64, 2)])
+def test_n19_schur_kcycle_solves_the_original_system(golden_dir, L, n_refine):
+    """tests/n19_wilson_kcycle_precond: right-block-Jacobi + Schur on every level, coarse operators built from the rbjacobi
+    stencil with their own rbjacobi variants.  The reference prints 'Check tolerance' = ||b - A x|| / ||b|| of the ORIGINAL
+    operator after reconstruct_M and expects it at the requested 1e-8 (n19:83,378-380)."""
+    gauge_file = os.path.join(golden_dir, "l%dt%db60_heatbath.dat" % (L, L))
+    out = subprocess.run([os.path.join(DRIVERS, "n19_wilson_kcycle_precond"), str(L), str(n_refine), gauge_file, str(L)], cwd=DRIVERS,
+                         env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+    iters = int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1))
+    res = float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
+    assert res <= 1.05e-8 and 0 < iters < 40
+
+
 @pytest.mark.parametrize("L,n_refine,coarse_dof,mass", [(64, 1, 8, -0.07), (64, 2, 8, -0.07), (32, 1, 4, -0.03)])
 def test_wilson_kcycle_matches_oracle(golden_dir, L, n_refine, coarse_dof, mass):
     gauge_file = os.path.join(golden_dir, "l%dt%db60_heatbath.dat" % (L, L))
