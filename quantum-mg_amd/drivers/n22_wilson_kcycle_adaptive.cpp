@@ -1,0 +1,286 @@
+// n22_wilson_kcycle_adaptive -- the build's counterpart of
+// tests/n22_wilson_kcycle_adaptive/wilson_kcycle.cpp on the GPU: adaptive multigrid setup, then the n13 solve.
+//   ./n22_wilson_kcycle_adaptive L mass beta n_refine n_setup [gauge_file] [tile] [solve_type]
+// Setup (n22:230-426):
+//   * initial hierarchy: per level, coarse_dof/2 gaussian vectors relaxed by 10 Richardson iterations
+//     (omega 0.33, n22:289, 664), Gram-Schmidt + normalise, chiral doubling, TransferMG (block-ortho x2),
+//     Galerkin coarse operator; lower levels by `build_coarse_by_restrict` (n22:628-706), which -- despite its
+//     name -- draws fresh gaussian vectors on each level;
+//   * n_setup adaptive passes (n22:336-426): on each level the test vector (level 0: the previous test vector;
+//     lower levels: the restriction of the finer level's test vector) is improved by 10 iterations of the
+//     CURRENT K-cycle (VPGCR, setup-time LevelSolve: 8 inner iterations, tol 1e-10, n22:245-247), the transfer
+//     and coarse operator of that level are rebuilt, and all lower levels are rebuilt from fresh vectors;
+//   * all setup operator counts are moved to the NullVec tracker (n22:428-431) and the LevelSolve parameters
+//     reset to the solve values (inner tol 0.2 / 1000 / 32).
+// Solve (n22:494-497): VPGCR tol 1e-10, 1000 its, restart 64, K-cycle preconditioner.  Prints the reference's
+// [QMG-OPS-STATS] / [QMG-ITER-STATS] lines (the reference prints the PreSmooth count under "PostSmooth" too,
+// n22:511; here the PostSmooth count is printed).
+// solve_type (optional, not in n22): "schur" builds rbjacobi stencils on every level and solves as n19 does --
+// the "red-black preconditioned" variant of BASELINE configs[4].
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "../include/qmg/qmg.hpp"
+
+using namespace std;
+
+static unsigned long long g_seed = 1337ull;
+
+struct Setup {
+  StatefulMultigridMG* mg;
+  complex<double>*** test_vectors;
+  int coarse_dof;
+  bool schur;
+};
+
+static MultigridMG::QMGMultigridPrecondStencil coarsen_from(const Setup& s) {
+  return s.schur ? MultigridMG::QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI : MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL;
+}
+static CoarseOperator2D::QMGCoarseBuildStencil build_extra(const Setup& s) {
+  return s.schur ? CoarseOperator2D::QMG_COARSE_BUILD_RBJACOBI : CoarseOperator2D::QMG_COARSE_BUILD_ORIGINAL;
+}
+
+// n22:628-706
+static TransferMG* build_coarse_by_restrict(Setup& s, int fine_level, Lattice2D* coarse_lat, StatefulMultigridMG::LevelSolveMG* new_level_solve,
+                                            bool fresh_build, inversion_verbose_struct& verb) {
+  StatefulMultigridMG* mg = s.mg;
+  const int fine_idx = fine_level, coarse_idx = fine_level + 1, coarse_dof = coarse_lat->get_nc();
+  const long n = mg->get_lattice(fine_idx)->get_size_cv_l();
+  complex<double>** null_vectors = new complex<double>*[coarse_dof];
+  for (int j = 0; j < coarse_dof / 2; j++) {
+    null_vectors[j] = allocate_vector<complex<double>>(n);
+    null_vectors[j + coarse_dof / 2] = allocate_vector<complex<double>>(n);
+    zero_vector(null_vectors[j], n);
+    zero_vector(null_vectors[j + coarse_dof / 2], n);
+    complex<double>* temp_rand = mg->get_storage(fine_idx)->check_out();
+    gaussian(temp_rand, n, g_seed++);
+    inversion_info invif = minv_vector_richardson(s.test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, 0.33, 250, apply_stencil_2D_M,
+                                                  (void*)mg->get_stencil(fine_idx), &verb);
+    mg->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count, fine_idx);
+    mg->get_storage(fine_idx)->check_in(temp_rand);
+    for (int k = 0; k < j; k++) orthogonal(s.test_vectors[fine_idx][j], s.test_vectors[fine_idx][k], n);
+    normalize(s.test_vectors[fine_idx][j], n);
+    copy_vector(null_vectors[j], s.test_vectors[fine_idx][j], n);
+    mg->get_stencil(fine_idx)->chiral_projection_both(null_vectors[j], null_vectors[j + coarse_dof / 2]);
+  }
+  TransferMG* transfer_obj = new TransferMG(mg->get_lattice(fine_idx), coarse_lat, null_vectors, true);
+  if (s.schur && !mg->get_stencil(fine_idx)->built_rbjacobi) mg->get_stencil(fine_idx)->build_rbjacobi_stencil();
+  if (fresh_build) mg->push_level(coarse_lat, transfer_obj, new_level_solve, true, true, coarsen_from(s), build_extra(s), null_vectors);
+  else mg->update_level(coarse_idx, coarse_lat, transfer_obj, new_level_solve, true, true, coarsen_from(s), build_extra(s), null_vectors);
+  for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
+  delete[] null_vectors;
+  return transfer_obj;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::cout << "Error: ./wilson_kcycle expects five arguments, L, mass, beta, n_refine, n_setup. Try mass = -0.075 for beta 6.0.\n";
+    return -1;
+  }
+  cout << setprecision(20);
+  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  const int x_len = stoi(argv[1]), y_len = x_len;
+  const double mass = stod(argv[2]);
+  const int n_refine = stoi(argv[4]);
+  const int n_setup = stoi(argv[5]);
+  const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
+  const int tile = (argc > 7) ? stoi(argv[7]) : 64;
+  const bool schur = (argc > 8) && string(argv[8]) == "schur";
+  const bool quiet = getenv("QMG_QUIET") != 0;
+  const int dof = Wilson2D::get_dof();
+  const int x_block = 4, y_block = 4, coarse_dof = 8;
+  const double tol = 1e-10; const int max_iter = 1000; const int restart_freq = 64;
+  const double inner_tol = 0.2; const int inner_max_iter = 1000; const int inner_restart_freq = 32;
+  const int n_pre_smooth = 2; const double pre_smooth_tol = 1e-15;
+  const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
+  const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
+  const QMGStencilType solve_type = schur ? QMG_MATVEC_RIGHT_SCHUR : QMG_MATVEC_ORIGINAL;
+
+  inversion_info invif;
+  inversion_verbose_struct verb;
+  verb.verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.verb_prefix = "Level 0: ";
+  verb.precond_verbosity = VERB_NONE;
+  verb.precond_verb_prefix = "Prec ";
+
+  Lattice2D** lats = new Lattice2D*[n_refine + 1];
+  lats[0] = new Lattice2D(x_len, y_len, dof);
+  Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
+  complex<double>* gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
+  bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
+  if (!got) return 3;
+  delete lat_gauge;
+
+  auto t_setup0 = std::chrono::steady_clock::now();
+  Wilson2D* wilson_op = new Wilson2D(lats[0], mass, gauge_field);
+  if (schur) wilson_op->build_rbjacobi_stencil();
+  StatefulMultigridMG::CoarsestSolveMG* coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
+  coarsest_solve_obj->coarsest_stencil_app = solve_type;
+  coarsest_solve_obj->coarsest_tol = coarsest_tol;
+  coarsest_solve_obj->coarsest_iters = coarsest_max_iter;
+  coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
+  StatefulMultigridMG* mg_object = new StatefulMultigridMG(lats[0], wilson_op, coarsest_solve_obj);
+
+  // lattices, test-vector storage, setup-time LevelSolve objects (n22:226-252)
+  StatefulMultigridMG::LevelSolveMG** level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
+  TransferMG** transfer_objs = new TransferMG*[n_refine];
+  complex<double>*** test_vectors = new complex<double>**[n_refine];
+  int cx = x_len, cy = y_len;
+  for (int i = 1; i <= n_refine; i++) {
+    const int fine_idx = i - 1;
+    cx /= x_block; cy /= y_block;
+    lats[i] = new Lattice2D(cx, cy, coarse_dof);
+    test_vectors[fine_idx] = new complex<double>*[coarse_dof / 2];
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      test_vectors[fine_idx][j] = allocate_vector<complex<double>>(lats[fine_idx]->get_size_cv_l());
+      zero_vector(test_vectors[fine_idx][j], lats[fine_idx]->get_size_cv_l());
+    }
+    transfer_objs[fine_idx] = 0;
+    level_solve_objs[fine_idx] = new StatefulMultigridMG::LevelSolveMG;
+    level_solve_objs[fine_idx]->fine_stencil_app = solve_type;
+    level_solve_objs[fine_idx]->intermediate_tol = 1e-10;
+    level_solve_objs[fine_idx]->intermediate_iters = 8;
+    level_solve_objs[fine_idx]->intermediate_restart_freq = 1024;
+    level_solve_objs[fine_idx]->pre_tol = pre_smooth_tol;
+    level_solve_objs[fine_idx]->pre_iters = n_pre_smooth;
+    level_solve_objs[fine_idx]->post_tol = post_smooth_tol;
+    level_solve_objs[fine_idx]->post_iters = n_post_smooth;
+  }
+  Setup S = {mg_object, test_vectors, coarse_dof, schur};
+
+  // initial level 0 -> 1 (n22:270-313): as build_coarse_by_restrict but with chirality-preserving doubling
+  {
+    const int fine_idx = 0, coarse_idx = 1;
+    const long n = lats[0]->get_size_cv_l();
+    complex<double>** null_vectors = new complex<double>*[coarse_dof];
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      null_vectors[j] = allocate_vector<complex<double>>(n);
+      null_vectors[j + coarse_dof / 2] = allocate_vector<complex<double>>(n);
+      zero_vector(null_vectors[j], n);
+      zero_vector(null_vectors[j + coarse_dof / 2], n);
+      complex<double>* temp_rand = mg_object->get_storage(fine_idx)->check_out();
+      gaussian(temp_rand, n, g_seed++);
+      invif = minv_vector_richardson(test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, 0.33, 250, apply_stencil_2D_M, (void*)mg_object->get_stencil(fine_idx), &verb);
+      mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count, fine_idx);
+      mg_object->get_storage(fine_idx)->check_in(temp_rand);
+      for (int k = 0; k < j; k++) orthogonal(test_vectors[fine_idx][j], test_vectors[fine_idx][k], n);
+      normalize(test_vectors[fine_idx][j], n);
+      copy_vector(null_vectors[j], test_vectors[fine_idx][j], n);
+      mg_object->get_stencil(fine_idx)->chiral_projection_both(null_vectors[j], null_vectors[j + coarse_dof / 2]);
+    }
+    transfer_objs[fine_idx] = new TransferMG(lats[fine_idx], lats[coarse_idx], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
+    mg_object->push_level(lats[coarse_idx], transfer_objs[fine_idx], level_solve_objs[fine_idx], true, true, coarsen_from(S), build_extra(S), null_vectors);
+    for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
+    delete[] null_vectors;
+  }
+  for (int i = 1; i < n_refine; i++) transfer_objs[i] = build_coarse_by_restrict(S, i, lats[i + 1], level_solve_objs[i], true, verb);
+
+  // adaptive passes (n22:336-426)
+  for (int m = 0; m < n_setup; m++) {
+    for (int i = 0; i < n_refine; i++) {
+      const int fine_idx = i, coarse_idx = i + 1;
+      const long n = lats[fine_idx]->get_size_cv_l();
+      complex<double>** null_vectors = new complex<double>*[coarse_dof];
+      for (int j = 0; j < coarse_dof / 2; j++) {
+        null_vectors[j] = allocate_vector<complex<double>>(n);
+        null_vectors[j + coarse_dof / 2] = allocate_vector<complex<double>>(n);
+        complex<double>* temp_rand = mg_object->get_storage(fine_idx)->check_out();
+        if (i == 0) copy_vector(temp_rand, test_vectors[fine_idx][j], n);
+        else { zero_vector(temp_rand, n); mg_object->get_transfer(fine_idx - 1)->restrict_f2c(test_vectors[fine_idx - 1][j], temp_rand); }
+        zero_vector(test_vectors[fine_idx][j], n);
+        // 10 iterations of the current K-cycle on this level (n22:373-376); n22 itself uses the ORIGINAL operator here
+        invif = minv_vector_gcr_var_precond(test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, apply_stencil_2D_M, (void*)mg_object->get_stencil(fine_idx),
+                                            schur ? (precond_op_cplx)0 : StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
+        mg_object->get_storage(fine_idx)->check_in(temp_rand);
+        mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count + 1, fine_idx);
+        cout << "[QMG-SETUP]: pass " << m << " level " << fine_idx << " test vector " << j << ": " << invif.iter << " K-cycle iterations, residual "
+             << sqrt(invif.resSq) << ", t = " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count() << " s" << std::endl;
+        zero_vector(null_vectors[j], n);
+        zero_vector(null_vectors[j + coarse_dof / 2], n);
+        for (int k = 0; k < j; k++) orthogonal(test_vectors[fine_idx][j], test_vectors[fine_idx][k], n);
+        normalize(test_vectors[fine_idx][j], n);
+        copy_vector(null_vectors[j], test_vectors[fine_idx][j], n);
+        mg_object->get_stencil(fine_idx)->chiral_projection_both(null_vectors[j], null_vectors[j + coarse_dof / 2]);
+      }
+      delete transfer_objs[fine_idx];
+      transfer_objs[fine_idx] = new TransferMG(lats[fine_idx], lats[coarse_idx], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
+      mg_object->update_level(coarse_idx, lats[coarse_idx], transfer_objs[fine_idx], level_solve_objs[fine_idx], true, true, coarsen_from(S), build_extra(S), null_vectors);
+      for (int j = i + 1; j < n_refine; j++) {
+        delete transfer_objs[j];
+        transfer_objs[j] = build_coarse_by_restrict(S, j, lats[j + 1], level_solve_objs[j], false, verb);
+      }
+      for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
+      delete[] null_vectors;
+      if (i < n_refine - 1) mg_object->go_coarser();
+    }
+    for (int i = 0; i < n_refine - 1; i++) mg_object->go_finer();
+    cout << "[QMG-SETUP]: adaptive pass " << m << " done\n";
+  }
+  for (int i = 0; i <= n_refine; i++) mg_object->shift_all_to_nullvec(i);
+  for (int i = 0; i < n_refine; i++) {   // solve-time parameters (n22:433-448)
+    level_solve_objs[i]->fine_stencil_app = solve_type;
+    level_solve_objs[i]->intermediate_tol = inner_tol;
+    level_solve_objs[i]->intermediate_iters = inner_max_iter;
+    level_solve_objs[i]->intermediate_restart_freq = inner_restart_freq;
+  }
+  qmg_stream_sync(0);
+  const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
+
+  const long n0 = lats[0]->get_size_cv_l();
+  complex<double>* b = mg_object->check_out(0);
+  gaussian(b, n0, g_seed++);
+  const double bnorm = sqrt(norm2sq(b, n0));
+  complex<double>* x = mg_object->check_out(0);
+  zero_vector(x, n0);
+  complex<double>* Ax = mg_object->check_out(0);
+  complex<double>* b_prep = mg_object->check_out(0);
+  zero_vector(b_prep, n0);
+  mg_object->get_stencil(0)->prepare_M(b_prep, b, solve_type);
+  const int solve_size = schur ? (int)(n0 / 2) : (int)n0;
+
+  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verb_prefix = "[QMG-MG-SOLVE-INFO]: Level 0 ";
+  auto t0 = std::chrono::steady_clock::now();
+  invif = minv_vector_gcr_var_precond_restart(x, b_prep, solve_size, max_iter, tol, restart_freq, Stencil2D::get_apply_function(solve_type),
+                                              (void*)mg_object->get_stencil(0), StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
+  qmg_stream_sync(0);
+  const double solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  mg_object->add_tracker_count(QMG_DSLASH_TYPE_KRYLOV, invif.ops_count, 0);
+  mg_object->add_iterations_count(invif.iter, 0);
+  cout << "Multigrid " << (invif.success ? "converged" : "failed to converge") << " in " << invif.iter << " iterations with alleged tolerance "
+       << sqrt(invif.resSq) / bnorm << ".\n";
+  for (int i = 0; i < n_refine + 1; i++)
+    std::cout << "[QMG-OPS-STATS]: Level " << i << " NullVec " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_NULLVEC, i) << " PreSmooth "
+              << mg_object->get_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, i) << " Krylov " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_KRYLOV, i)
+              << " PostSmooth " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, i) << " Total " << mg_object->get_total_count(i) << "\n";
+  std::vector<double> avg_iter = mg_object->query_average_iterations();
+  for (int i = 0; i < n_refine + 1; i++) std::cout << "[QMG-ITER-STATS]: Level " << i << " AverageIters " << avg_iter[i] << "\n";
+  complex<double>* x_rec = mg_object->check_out(0);
+  zero_vector(x_rec, n0);
+  mg_object->get_stencil(0)->reconstruct_M(x_rec, x, b, solve_type);
+  zero_vector(Ax, n0);
+  mg_object->apply_stencil(Ax, x_rec, 0);
+  const double true_res = sqrt(diffnorm2sq(b, Ax, n0)) / bnorm;
+  cout << "Check tolerance " << true_res << "\n";
+  cout << setprecision(6) << "[QMG-TIMING]: setup " << setup_s << " s ; solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
+  mg_object->check_in(x_rec, 0); mg_object->check_in(b_prep, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
+
+  const bool ok_ = invif.success && true_res < 20 * tol;
+  delete mg_object;
+  for (int i = 0; i < n_refine; i++) {
+    delete transfer_objs[i]; delete level_solve_objs[i];
+    for (int j = 0; j < coarse_dof / 2; j++) deallocate_vector(&test_vectors[i][j]);
+    delete[] test_vectors[i];
+  }
+  delete[] test_vectors; delete[] transfer_objs; delete[] level_solve_objs; delete coarsest_solve_obj;
+  delete wilson_op;
+  for (int i = 0; i <= n_refine; i++) delete lats[i];
+  delete[] lats;
+  deallocate_vector(&gauge_field);
+  qmg::VecPool::release_all();
+  return ok_ ? 0 : 1;
+}
