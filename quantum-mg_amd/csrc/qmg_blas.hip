@@ -123,21 +123,23 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const cplx* __restrict__ x, co
   block_reduce_store<2, OP == RED_NORMINF>(v, partials + 2 * blockIdx.x);
 }
 
-// stage 2: one block sums nparts partials of width `width` in a fixed order
+// stage 2: block q sums the nparts partials of output q in a fixed order (grid = width: a 32-vector multidot has 64
+// outputs and they are reduced concurrently, not one after the other)
 template <bool MAX, bool SQRT>
 __global__ __launch_bounds__(BLOCK) void k_reduce_final(const double* __restrict__ partials, int nparts, int stride, int width, double* __restrict__ out) {
-  __shared__ double sm[BLOCK];
-  for (int q = 0; q < width; q++) {
-    double t = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += BLOCK) t = MAX ? fmax(t, partials[(long)i * stride + q]) : t + partials[(long)i * stride + q];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    for (int s = BLOCK / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) sm[threadIdx.x] = MAX ? fmax(sm[threadIdx.x], sm[threadIdx.x + s]) : sm[threadIdx.x] + sm[threadIdx.x + s];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[q] = SQRT ? sqrt(sm[0]) : sm[0];
-    __syncthreads();
+  __shared__ double sm[BLOCK / WAVE];
+  const int q = blockIdx.x;
+  if (q >= width) return;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += BLOCK) t = MAX ? fmax(t, partials[(long)i * stride + q]) : t + partials[(long)i * stride + q];
+  t = MAX ? wave_max(t) : wave_sum(t);
+  if ((threadIdx.x & (WAVE - 1)) == 0) sm[threadIdx.x / WAVE] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / WAVE; w++) r = MAX ? fmax(r, sm[w]) : r + sm[w];
+    out[q] = SQRT ? sqrt(r) : r;
   }
 }
 
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(BLOCK) void k_timeslice(const cplx* __restrict__ a,
 struct RedWorkspace {
   double* partials = nullptr;   // RED_BLOCKS * 2 * RED_MAXK doubles
   double* result = nullptr;     // 2 * RED_MAXK doubles
+  double* pinned = nullptr;     // host-pinned, device-visible: the final kernel writes host results straight here
   int device = -1;
 };
 static thread_local RedWorkspace g_ws;
@@ -206,6 +209,7 @@ static int get_ws(RedWorkspace** out) {
     // (leaks the previous device's few hundred KB if a thread hops devices; one rank = one device here)
     QMG_HIP_CHECK(hipMalloc((void**)&g_ws.partials, sizeof(double) * RED_BLOCKS * 2 * RED_MAXK));
     QMG_HIP_CHECK(hipMalloc((void**)&g_ws.result, sizeof(double) * 2 * RED_MAXK));
+    QMG_HIP_CHECK(hipHostMalloc((void**)&g_ws.pinned, sizeof(double) * 2 * RED_MAXK, hipHostMallocDefault));
     g_ws.device = dev;
   }
   *out = &g_ws;
@@ -219,12 +223,20 @@ static unsigned red_grid(long n) {
   return (unsigned)b;
 }
 
+// Host results: when the caller wants the value on the host only, the final kernel has written it into the
+// pinned, device-visible buffer; one stream synchronise makes it readable -- no D2H copy on the critical path
+// of a Krylov iteration.
 static int finish(double* result_dev, int width, double* out_dev, double* out_host, hipStream_t st) {
   if (out_dev && out_dev != result_dev)
     QMG_HIP_CHECK(hipMemcpyAsync(out_dev, result_dev, sizeof(double) * width, hipMemcpyDeviceToDevice, st));
   if (out_host) {
-    QMG_HIP_CHECK(hipMemcpyAsync(out_host, result_dev, sizeof(double) * width, hipMemcpyDeviceToHost, st));
-    QMG_HIP_CHECK(hipStreamSynchronize(st));
+    if (result_dev == g_ws.pinned) {
+      QMG_HIP_CHECK(hipStreamSynchronize(st));
+      memcpy(out_host, g_ws.pinned, sizeof(double) * width);
+    } else {
+      QMG_HIP_CHECK(hipMemcpyAsync(out_host, result_dev, sizeof(double) * width, hipMemcpyDeviceToHost, st));
+      QMG_HIP_CHECK(hipStreamSynchronize(st));
+    }
   }
   return QMG_SUCCESS;
 }
@@ -240,9 +252,9 @@ static int reduce2(const void* x, const void* y, size_t n, int width, double* ou
   const unsigned g = red_grid((long)n);
   k_reduce<OP><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
   QMG_LAUNCH_CHECK();
-  double* res = out_dev ? out_dev : ws->result;
-  if (OP == RED_NORMINF) k_reduce_final<true, true><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
-  else k_reduce_final<false, false><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
+  double* res = out_dev ? out_dev : ws->pinned;
+  if (OP == RED_NORMINF) k_reduce_final<true, true><<<width, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
+  else k_reduce_final<false, false><<<width, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
   QMG_LAUNCH_CHECK();
   return finish(res, width, nullptr, out_host, st);
 }
@@ -365,8 +377,8 @@ int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* 
     else { k_multidot<1><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 1; }
     QMG_LAUNCH_CHECK();
   }
-  double* res = out_dev ? out_dev : ws->result;
-  k_reduce_final<false, false><<<1, BLOCK, 0, st>>>(ws->partials, (int)g, 2 * k, 2 * k, res);
+  double* res = out_dev ? out_dev : ws->pinned;
+  k_reduce_final<false, false><<<2 * k, BLOCK, 0, st>>>(ws->partials, (int)g, 2 * k, 2 * k, res);
   QMG_LAUNCH_CHECK();
   return finish(res, 2 * k, nullptr, out_host, st);
 }

@@ -181,6 +181,48 @@ def test_every_piece_mask_every_kernel(name, pieces, Lx, Ly, nc):
     assert cs.rel_l2(got, want) < TOL
 
 
+@pytest.mark.parametrize("Lx,Ly,nc", [(2, 2, 1), (2, 2, 2), (2, 2, 8), (2, 4, 2), (4, 2, 3), (2, 6, 24)])
+def test_minimum_lattices(Lx, Ly, nc):
+    """The smallest lattices the reference's cshift admits (both extents even, cshift_2d.h:62): on a 2-wide lattice the +x
+    and -x neighbours are the SAME site (half-row length 1), as on the coarsest level of an n19-style hierarchy."""
+    vol = Lx * Ly
+    clover = cs.gaussian_cvec(vol * nc * nc, 1)
+    hopping = cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    rhs = cs.gaussian_cvec(vol * nc, 3)
+    lhs0 = cs.gaussian_cvec(vol * nc, 4)
+    for pieces in (ol.P_ALL | ol.P_ZERO, ol.P_ALL, ol.P_EO, ol.P_OE | ol.P_ZERO_O, (ol.P_EO_XP1 << 2) | (ol.P_OE_XP1 << 2)):
+        want, got = _apply_both(Lx, Ly, nc, clover, hopping, rhs, pieces, (0.1, 0.02, 0.0), lhs0)
+        assert cs.rel_l2(got, want) < TOL, pieces
+
+
+def test_zero_length_and_strided_inputs():
+    """Empty inputs are accepted and do nothing; multi-RHS batches may be padded (vec_stride > size_cv)."""
+    import ctypes as C
+    v = qmg.DeviceArray.zeros(16)
+    L = qmg.lib()
+    assert L.qmg_caxpy(C.c_double(1.0), C.c_double(0.0), C.c_void_p(v.ptr), C.c_void_p(v.ptr), C.c_size_t(0), None) == 0
+    assert L.qmg_zero_vector(None, C.c_size_t(0), None) == 0
+    out = C.c_double(-1.0)
+    assert L.qmg_norm2sq(C.c_void_p(v.ptr), C.c_size_t(0), None, C.byref(out), None) == 0 and out.value == 0.0
+    assert L.qmg_multi_caxpy(None, None, 0, C.c_void_p(v.ptr), C.c_size_t(16), None) == 0
+    assert not v.to_host().any()
+    Lx, Ly, nc, nrhs, pad = 8, 6, 2, 3, 5
+    vol = Lx * Ly
+    size, stride = vol * nc, vol * nc + pad
+    clover, hopping = cs.gaussian_cvec(vol * nc * nc, 1), cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    rhs = cs.gaussian_cvec(stride * nrhs, 3)
+    sentinel = np.full(stride * nrhs, 9.0 - 2.0j)
+    od = ol.make_desc(Lx, Ly, nc, clover, hopping, 0.1)
+    gd = qmg.make_desc(Lx, Ly, nc, D(clover), D(hopping), 0.1)
+    dl = D(sentinel)
+    qmg.stencil_apply(gd, dl, D(rhs), nrhs=nrhs, vec_stride=stride)
+    got = dl.to_host()
+    for k in range(nrhs):
+        want = ol.stencil_apply(od, np.ascontiguousarray(rhs[k * stride:k * stride + size]))
+        assert cs.rel_l2(got[k * stride:k * stride + size], want) < TOL
+        assert np.all(got[k * stride + size:(k + 1) * stride] == 9.0 - 2.0j)      # padding untouched
+
+
 @pytest.mark.parametrize("nc", [1, 2, 8])
 def test_missing_clover_or_hopping(nc):
     Lx, Ly = 16, 8
