@@ -178,6 +178,11 @@ int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
 int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
                              void* cholesky, void* stream);
 
+/* block_bi_orthonormalize, one pass, in place (:610-769): separate prolongator / restrictor vectors made block
+ * bi-orthonormal (R^dag P = 1 per block); block_L / block_U (cLx*cLy*nvec*nvec complex each) may be NULL. */
+int qmg_block_bi_orthonormalize(void* prolong_vecs, void* restrict_vecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
+                                void* block_L, void* block_U, void* stream);
+
 /* ---------------- Galerkin coarse operator (operators/coarse.h:90-444) ---------------- */
 int qmg_coarse_build(void* coarse_clover, void* coarse_hopping, const qmg_stencil_desc* fine,
                      const void* nullvecs, const void* restrict_vecs /* or NULL */,

@@ -567,6 +567,51 @@ int qo_block_orthonormalize(double* nullvecs_, int nvec, int fLx, int fLy, int f
   return 0;
 }
 
+// block_bi_orthonormalize (transfer.h:610-769): two-sided Gram-Schmidt per block, written with single-vector
+// restrict / prolong; normalisation splits <r_i,p_i> = |z| e^{i phi} as r_i <- r_i e^{i phi}/sqrt|z| (restrict conjugates
+// it), p_i <- p_i / sqrt|z|.  L collects <p_j, r_i> (conjugated at the end, :757), U collects <r_j, p_i>.
+int qo_block_bi_orthonormalize(double* pvecs_, double* rvecs_, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy, double* L_, double* U_) {
+  const long fsize = (long)fLx * fLy * fnc;
+  const int cvol = cLx * cLy, cnc = nvec;
+  const long csize = (long)cvol * cnc;
+  cplx* P = C(pvecs_);
+  cplx* R = C(rvecs_);
+  cplx* Lm = L_ ? C(L_) : nullptr;
+  cplx* Um = U_ ? C(U_) : nullptr;
+  std::vector<cplx> fine1((size_t)fsize), coarse2((size_t)csize);
+  auto zero = [&]() { std::fill(fine1.begin(), fine1.end(), cplx(0.0)); std::fill(coarse2.begin(), coarse2.end(), cplx(0.0)); };
+  for (int i = 0; i < nvec; i++) {
+    for (int j = 0; j < i; j++) {
+      zero();
+      qo_restrict((double*)(R + j * fsize), 1, (double*)(P + i * fsize), (double*)coarse2.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+      if (Um) for (int s = 0; s < cvol; s++) Um[(long)s * cnc * cnc + j * cnc + i] = coarse2[(long)s * cnc];
+      qo_prolong((double*)(P + j * fsize), 1, (double*)coarse2.data(), (double*)fine1.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+      caxpy(-1.0, fine1.data(), P + i * fsize, fsize);
+      zero();
+      qo_restrict((double*)(P + j * fsize), 1, (double*)(R + i * fsize), (double*)coarse2.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+      if (Lm) for (int s = 0; s < cvol; s++) Lm[(long)s * cnc * cnc + i * cnc + j] = coarse2[(long)s * cnc];
+      qo_prolong((double*)(R + j * fsize), 1, (double*)coarse2.data(), (double*)fine1.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+      caxpy(-1.0, fine1.data(), R + i * fsize, fsize);
+    }
+    zero();
+    qo_restrict((double*)(R + i * fsize), 1, (double*)(P + i * fsize), (double*)coarse2.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+    for (int s = 0; s < cvol; s++) {   // only colour 0 of each coarse site is used below
+      const cplx z = coarse2[(long)s * cnc];
+      coarse2[(long)s * cnc] = std::polar(1.0 / std::sqrt(std::abs(z)), std::arg(z));
+    }
+    if (Lm) for (int s = 0; s < cvol; s++) Lm[(long)s * cnc * cnc + i * (cnc + 1)] = 1.0 / coarse2[(long)s * cnc];
+    qo_prolong((double*)(R + i * fsize), 1, (double*)coarse2.data(), (double*)fine1.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+    std::memcpy((void*)(R + i * fsize), fine1.data(), sizeof(cplx) * fsize);
+    std::fill(fine1.begin(), fine1.end(), cplx(0.0));
+    for (int s = 0; s < cvol; s++) coarse2[(long)s * cnc] = std::abs(coarse2[(long)s * cnc]);
+    if (Um) for (int s = 0; s < cvol; s++) Um[(long)s * cnc * cnc + i * (cnc + 1)] = 1.0 / coarse2[(long)s * cnc];
+    qo_prolong((double*)(P + i * fsize), 1, (double*)coarse2.data(), (double*)fine1.data(), fLx, fLy, fnc, cLx, cLy, cnc);
+    std::memcpy((void*)(P + i * fsize), fine1.data(), sizeof(cplx) * fsize);
+  }
+  if (Lm) for (long k = 0; k < (long)cvol * cnc * cnc; k++) Lm[k] = std::conj(Lm[k]);
+  return 0;
+}
+
 // ---------------- Galerkin coarse operator (coarse.h:90-444) ----------------
 // For each coarse colour: one clover probe (all coarse sites) and, per direction and per source
 // parity, one hopping probe.  Same-parity results go to the coarse clover, other-parity results to

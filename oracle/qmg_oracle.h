@@ -116,6 +116,9 @@ int qo_restrict(const double* nullvecs, int nvec, const double* fine, double* co
 /* in-place block Gram-Schmidt, one pass (transfer.h:514-607); cholesky may be NULL */
 int qo_block_orthonormalize(double* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy, double* cholesky);
 
+/* in-place block bi-orthonormalisation, one pass (transfer.h:610-769); L, U may be NULL */
+int qo_block_bi_orthonormalize(double* pvecs, double* rvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy, double* block_L, double* block_U);
+
 /* ---- operators/coarse.h:90-444 : Galerkin coarse stencil by 9*nc probes ---- */
 int qo_coarse_build(double* cclover, double* chopping, const qo_stencil_desc* fine,
                     const double* nullvecs, const double* restrict_vecs /*or NULL*/,

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
-    "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
+    "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
 ]
 
@@ -316,6 +316,10 @@ def restrict(nullvecs, nvec, fine, coarse, fdims, cdims):
 
 def block_orthonormalize(nullvecs, nvec, fdims, cLx, cLy, cholesky=None):
     check(lib().qmg_block_orthonormalize(_vp(nullvecs), nvec, *fdims, cLx, cLy, _vp(cholesky), None), "qmg_block_orthonormalize")
+
+
+def block_bi_orthonormalize(pvecs, rvecs, nvec, fdims, cLx, cLy, block_L=None, block_U=None):
+    check(lib().qmg_block_bi_orthonormalize(_vp(pvecs), _vp(rvecs), nvec, *fdims, cLx, cLy, _vp(block_L), _vp(block_U), None), "qmg_block_bi_orthonormalize")
 
 
 def coarse_build(cclover, chopping, fdesc, nullvecs, cdims, restrict_vecs=None):

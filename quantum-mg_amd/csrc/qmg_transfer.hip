@@ -154,6 +154,19 @@ __global__ __launch_bounds__(BLOCK) void k_restrict_generic(const cplx* __restri
 __global__ __launch_bounds__(BLOCK) void k_inv_real_sqrt(cplx* __restrict__ v, long n) {
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) v[i] = cmake(1.0 / sqrt(v[i].x), 0.0);
 }
+// bi-ortho helpers (transfer.h:366-380, 707, 736): MODE 0: z -> polar(1/sqrt|z|, arg z) ; 1: z -> |z| ; 2: z -> conj z.
+// (MODE is a template parameter on purpose: with a run-time three-way branch hipcc 7.2 -O3 emitted code whose
+//  mode-2 path stored a zero imaginary part -- seen in the ISA and caught by the parity test.)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_elementwise(cplx* __restrict__ v, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const cplx z = v[i];
+    if (MODE == 2) { v[i] = cmake(z.x, -z.y); continue; }
+    const double a = sqrt(z.x * z.x + z.y * z.y);
+    if (MODE == 0) { const double s = 1.0 / (a * sqrt(a)); v[i] = cmake(z.x * s, z.y * s); }
+    else v[i] = cmake(a, 0.0);
+  }
+}
 // chol[site*nc2 + off] = src[site*cnc] (or its inverse)   (copy_vector_blas at transfer.h:560,592)
 __global__ __launch_bounds__(BLOCK) void k_chol_store(cplx* __restrict__ chol, const cplx* __restrict__ src, long cvol, int cnc, int off, int invert) {
   for (long s = (long)blockIdx.x * BLOCK + threadIdx.x; s < cvol; s += (long)gridDim.x * BLOCK) {
@@ -286,6 +299,63 @@ int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc
     if (rc) break;
     hipMemcpyAsync(nv + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);   // :601
   }
+  hipStreamSynchronize(st);
+  hipFree(fine1);
+  hipFree(coarse2);
+  if (!rc) QMG_LAUNCH_CHECK();
+  return rc;
+}
+
+// block_bi_orthonormalize, one pass, in place (transfer.h:610-769): the asymmetric (P != R^dag) counterpart.
+// pvecs = prolongator vectors, rvecs = restrictor vectors; afterwards R^dag P = 1 block by block.
+// block_L / block_U (coarse size_cm each) may be NULL.
+int qmg_block_bi_orthonormalize(void* pvecs, void* rvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
+                                void* block_L, void* block_U, void* stream) {
+  if (!pvecs || !rvecs || nvec < 1) return QMG_ERR_INVALID;
+  XferGeom g;
+  const int cnc = nvec;
+  int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const long fsize = g.fsize, cvol = 2 * g.chalf_vol, csize = cvol * cnc;
+  cplx* P = (cplx*)pvecs;
+  cplx* R = (cplx*)rvecs;
+  cplx *fine1 = nullptr, *coarse2 = nullptr;
+  QMG_HIP_CHECK(hipMalloc((void**)&fine1, sizeof(cplx) * fsize));
+  QMG_HIP_CHECK(hipMalloc((void**)&coarse2, sizeof(cplx) * csize));
+  auto zero = [&]() { hipMemsetAsync(fine1, 0, sizeof(cplx) * fsize, st); hipMemsetAsync(coarse2, 0, sizeof(cplx) * csize, st); };
+  rc = QMG_SUCCESS;
+  for (int i = 0; i < nvec && !rc; i++) {
+    for (int j = 0; j < i && !rc; j++) {
+      zero();
+      rc = launch_restrict(R + j * fsize, 1, P + i * fsize, coarse2, g, st);                                        // <r_j, p_i>  (:643)
+      if (!rc && block_U) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_U, coarse2, cvol, cnc, j * cnc + i, 0);   // :651
+      if (!rc) rc = launch_prolong(P + j * fsize, 1, coarse2, fine1, g, st);                                        // :656
+      if (!rc) rc = qmg_caxpy(-1.0, 0.0, fine1, P + i * fsize, (size_t)fsize, stream);                              // :660
+      if (rc) break;
+      zero();
+      rc = launch_restrict(P + j * fsize, 1, R + i * fsize, coarse2, g, st);                                        // <p_j, r_i>  (:668)
+      if (!rc && block_L) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_L, coarse2, cvol, cnc, i * cnc + j, 0);   // :678
+      if (!rc) rc = launch_prolong(R + j * fsize, 1, coarse2, fine1, g, st);                                        // :683
+      if (!rc) rc = qmg_caxpy(-1.0, 0.0, fine1, R + i * fsize, (size_t)fsize, stream);                              // :687
+    }
+    if (rc) break;
+    zero();
+    rc = launch_restrict(R + i * fsize, 1, P + i * fsize, coarse2, g, st);                                          // <r_i, p_i>  (:699)
+    if (rc) break;
+    k_elementwise<0><<<grid_1d((size_t)csize), BLOCK, 0, st>>>(coarse2, csize);                                     // inv_phase_abs_sqrt (:703)
+    if (block_L) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_L, coarse2, cvol, cnc, i * (cnc + 1), 1);   // :708-719
+    rc = launch_prolong(R + i * fsize, 1, coarse2, fine1, g, st);                                                   // :724
+    if (rc) break;
+    hipMemcpyAsync(R + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);                        // :727
+    hipMemsetAsync(fine1, 0, sizeof(cplx) * fsize, st);
+    k_elementwise<1><<<grid_1d((size_t)csize), BLOCK, 0, st>>>(coarse2, csize);                                     // abs_vector (:731)
+    if (block_U) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_U, coarse2, cvol, cnc, i * (cnc + 1), 1);   // :735-742
+    rc = launch_prolong(P + i * fsize, 1, coarse2, fine1, g, st);                                                   // :747
+    if (rc) break;
+    hipMemcpyAsync(P + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);                        // :750
+  }
+  if (!rc && block_L) k_elementwise<2><<<grid_1d((size_t)cvol * cnc * cnc), BLOCK, 0, st>>>((cplx*)block_L, cvol * cnc * cnc);   // conj L (:757)
   hipStreamSynchronize(st);
   hipFree(fine1);
   hipFree(coarse2);

@@ -80,8 +80,8 @@ class TransferMG {
     is_init = true;
   }
 
-  // Separate prolongator / restrictor (:185-230).  Block BI-orthonormalisation (:610-769) is not built yet:
-  // the vectors are used as given and a request for it is reported.
+  // Separate prolongator / restrictor (:185-230): block BI-orthonormalisation (:610-769) so that R^dag P = 1 per block;
+  // run twice, the LU factors saved on the first pass only (:208-225).
   TransferMG(Lattice2D* in_fine_lat, Lattice2D* in_coarse_lat, complex<double>** in_prolong_null_vectors,
              complex<double>** in_restrict_null_vectors, bool do_block_bi_ortho = true, bool save_decomp = false,
              QMGDoublingType in_doubling = QMG_DOUBLE_NONE)
@@ -90,8 +90,18 @@ class TransferMG {
     restrict_store = copy_in(in_restrict_null_vectors);
     restrict_null_vectors = new complex<double>*[const_num_null_vec];
     for (int i = 0; i < const_num_null_vec; i++) restrict_null_vectors[i] = restrict_store + (long)i * fine_lat->get_size_cv_l();
-    if (do_block_bi_ortho || save_decomp)
-      std::cout << "[QMG-ERROR]: TransferMG: block bi-orthonormalization is not available on the device path yet; vectors used as given.\n";
+    if (save_decomp) {
+      block_L = allocate_vector<complex<double>>(coarse_lat->get_size_cm_l());
+      block_U = allocate_vector<complex<double>>(coarse_lat->get_size_cm_l());
+      zero_vector(block_L, coarse_lat->get_size_cm_l());
+      zero_vector(block_U, coarse_lat->get_size_cm_l());
+    }
+    if (do_block_bi_ortho) {
+      for (int pass = 0; pass < 2; pass++)
+        qmg::ok(qmg_block_bi_orthonormalize(null_store, restrict_store, const_num_null_vec, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1),
+                                            fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), pass == 0 ? block_L : 0,
+                                            pass == 0 ? block_U : 0, qmg::current_stream()), "qmg_block_bi_orthonormalize");
+    }
   }
 
   ~TransferMG() {

@@ -227,6 +227,13 @@ def block_orthonormalize(nullvecs, fdims, cdims, cholesky=None):
     return nullvecs
 
 
+def block_bi_orthonormalize(pvecs, rvecs, fdims, cdims, block_L=None, block_U=None):
+    fLx, fLy, fnc = fdims
+    cLx, cLy, cnc = cdims
+    assert lib().qo_block_bi_orthonormalize(_p(pvecs), _p(rvecs), cnc, fLx, fLy, fnc, cLx, cLy, _p(block_L), _p(block_U)) == 0
+    return pvecs, rvecs
+
+
 def coarse_build(fdesc, nullvecs, cdims, restrict_vecs=None):
     cLx, cLy, cnc = cdims
     ccm = cLx * cLy * cnc * cnc

@@ -446,6 +446,36 @@ def test_block_orthonormalize_and_n05_identities(fdims, cdims):
     assert cs.rel_l2(dc.to_host(), vc) < 1e-13
 
 
+@pytest.mark.parametrize("fdims,cdims", XFER_CASES[:4])
+def test_block_bi_orthonormalize_asymmetric_transfer(fdims, cdims):
+    """transfer.h:610-769 (P != R^dag, tests/n05_prolong_restrict_test:105-139): after bi-orthonormalisation R^dag P = 1
+    on the coarse space; L and U reproduce the block Gram matrix R^dag P of the ORIGINAL vectors."""
+    fsize, csize = fdims[0] * fdims[1] * fdims[2], cdims[0] * cdims[1] * cdims[2]
+    nvec = cdims[2]
+    pv = cs.gaussian_cvec(nvec * fsize, 1)
+    rv = pv + 0.3 * cs.gaussian_cvec(nvec * fsize, 2)          # restrictor vectors close to, but not equal to, the prolongator's
+    cm = cdims[0] * cdims[1] * nvec * nvec
+    Lh, Uh = np.zeros(cm, dtype=np.complex128), np.zeros(cm, dtype=np.complex128)
+    wp, wr = ol.block_bi_orthonormalize(pv.copy(), rv.copy(), fdims, cdims, Lh, Uh)
+    dp, dr, dL, dU = D(pv), D(rv), qmg.DeviceArray.zeros(cm), qmg.DeviceArray.zeros(cm)
+    qmg.block_bi_orthonormalize(dp, dr, nvec, fdims, cdims[0], cdims[1], dL, dU)
+    assert cs.rel_l2(dp.to_host(), wp) < 1e-11 and cs.rel_l2(dr.to_host(), wr) < 1e-11
+    assert cs.rel_l2(dL.to_host(), Lh) < 1e-11 and cs.rel_l2(dU.to_host(), Uh) < 1e-11
+    qmg.block_bi_orthonormalize(dp, dr, nvec, fdims, cdims[0], cdims[1])          # second pass, as the constructor does
+    vc = cs.gaussian_cvec(csize, 7)
+    df, dc = qmg.DeviceArray.zeros(fsize), qmg.DeviceArray.zeros(csize)
+    qmg.prolong(dp, nvec, D(vc), df, fdims, cdims)
+    qmg.restrict(dr, nvec, df, dc, fdims, cdims)
+    assert cs.rel_l2(dc.to_host(), vc) < 1e-12
+    # L U = block Gram matrix of the original vectors: G[s][i][j] = sum_{k in block s} conj(r_i[k]) p_j[k]
+    m = ol.transfer_build_map(fdims[0], fdims[1], fdims[2], cdims[0], cdims[1])
+    P0, R0 = pv.reshape(nvec, fsize), rv.reshape(nvec, fsize)
+    Lg, Ug = dL.to_host().reshape(-1, nvec, nvec), dU.to_host().reshape(-1, nvec, nvec)
+    for s_ in range(0, m.shape[0], max(1, m.shape[0] // 5)):
+        G = np.conj(R0[:, m[s_]]) @ P0[:, m[s_]].T
+        assert np.allclose(Lg[s_] @ Ug[s_], G, rtol=1e-10, atol=1e-10)
+
+
 @pytest.mark.parametrize("fdims,cdims", [((16, 16, 2), (4, 4, 4)), ((8, 8, 4), (4, 2, 6)), ((16, 8, 1), (4, 4, 2))])
 def test_coarse_build_matches_oracle_and_n08_galerkin(fdims, cdims):
     fLx, fLy, fnc = fdims
