@@ -420,6 +420,7 @@ static int g_stencil_nt = 3;     // tuning knob: bit0 non-temporal matrix loads,
 static int g_stencil_ablate = 0;
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
+static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
 static GenLayout make_gen_layout(int nc, int hr) {
   GenLayout L;
@@ -427,6 +428,7 @@ static GenLayout make_gen_layout(int nc, int hr) {
   int S = (BLOCK * GEN_MAX_PER_THREAD) / nc2;       // registers: S*nc^2 <= 256*12
   if (S > BLOCK / nc) S = BLOCK / nc;               // one (s,r) row per thread at least
   if (S > hr) S = hr;
+  if (g_gen_sites > 0 && S > g_gen_sites) S = g_gen_sites;
   if (S < 1) S = 1;
   L.S = S;
   int H = BLOCK / (S * nc);
@@ -449,6 +451,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 

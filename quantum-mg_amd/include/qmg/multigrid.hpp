@@ -417,17 +417,18 @@ class StatefulMultigridMG : public MultigridMG {
       if (pre_cgne && (fine_type == QMG_MATVEC_ORIGINAL || fine_type == QMG_MATVEC_RIGHT_JACOBI)) {
         complex<double>* z1_prec = fine_storage->check_out();
         zero_vector(z1_prec, fine_size);
+        qmg::zero_guess_flag() = true;   // the iterate was zeroed just above: r0 = rhs, no A*0 (krylov.hpp)
         invif = minv_vector_minres(z1_prec, rhs, (int)fine_size_solve, n_pre_smooth, pre_smooth_tol, 0.85,
                                    Stencil2D::get_apply_function(fine_type == QMG_MATVEC_ORIGINAL ? QMG_MATVEC_M_MDAGGER : QMG_MATVEC_RBJ_M_MDAGGER), (void*)fine_stencil);
         fine_stencil->apply_M(z1, z1_prec, fine_type == QMG_MATVEC_ORIGINAL ? QMG_MATVEC_DAGGER : QMG_MATVEC_RBJ_DAGGER);
         mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, 2 * invif.ops_count + 1, level);
         fine_storage->check_in(z1_prec);
       } else {
+        qmg::zero_guess_flag() = true;   // the iterate was zeroed just above: r0 = rhs, no A*0 (krylov.hpp)
         invif = minv_vector_minres(z1, rhs, (int)fine_size_solve, n_pre_smooth, pre_smooth_tol, 0.85, apply_fine_M, (void*)fine_stencil);
         mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, invif.ops_count, level);
       }
-      zero_vector(Atmp, fine_size);
-      fine_stencil->apply_M(Atmp, z1, fine_type);
+      apply_fine_M(Atmp, z1, (void*)fine_stencil);   // = zero_vector + apply_M(.., fine_type), one launch for ORIGINAL
       mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, 1, level);
       caxpbyz(1.0, rhs, -1.0, Atmp, r1, fine_size_solve);
     } else {
@@ -451,6 +452,7 @@ class StatefulMultigridMG : public MultigridMG {
     complex<double>* e_coarse = coarse_storage->check_out();
     zero_vector(e_coarse, coarse_size);
     const double inner_tol = (rnorm_prep > 0.0) ? coarse_tol * rnorm / rnorm_prep : coarse_tol;
+    qmg::zero_guess_flag() = true;   // e_coarse was zeroed just above; consumed by whichever solver runs next
     if (level == total_num_levels - 2) {
       const bool coarsest_normal = (coarse_type == QMG_MATVEC_M_MDAGGER || coarse_type == QMG_MATVEC_MDAGGER_M ||
                                     coarse_type == QMG_MATVEC_RBJ_M_MDAGGER || coarse_type == QMG_MATVEC_RBJ_MDAGGER_M);
@@ -500,8 +502,7 @@ class StatefulMultigridMG : public MultigridMG {
 
     // ---- 4. post-smooth on r2 = rhs - A lhs (:1023-1056)
     if (n_post_smooth > 0) {
-      zero_vector(Atmp, fine_size);
-      fine_stencil->apply_M(Atmp, lhs, fine_type);
+      apply_fine_M(Atmp, lhs, (void*)fine_stencil);
       complex<double>* r2 = fine_storage->check_out();
       caxpbyz(1.0, rhs, -1.0, Atmp, r2, fine_size_solve);
       complex<double>* z3 = fine_storage->check_out();
@@ -509,12 +510,14 @@ class StatefulMultigridMG : public MultigridMG {
       if (post_cgne && (fine_type == QMG_MATVEC_ORIGINAL || fine_type == QMG_MATVEC_RIGHT_JACOBI)) {
         complex<double>* z3_prec = fine_storage->check_out();
         zero_vector(z3_prec, fine_size);
+        qmg::zero_guess_flag() = true;   // the iterate was zeroed just above: r0 = rhs, no A*0 (krylov.hpp)
         invif = minv_vector_minres(z3_prec, r2, (int)fine_size_solve, n_post_smooth, post_smooth_tol, 0.85,
                                    Stencil2D::get_apply_function(fine_type == QMG_MATVEC_ORIGINAL ? QMG_MATVEC_M_MDAGGER : QMG_MATVEC_RBJ_M_MDAGGER), (void*)fine_stencil);
         fine_stencil->apply_M(z3, z3_prec, fine_type == QMG_MATVEC_ORIGINAL ? QMG_MATVEC_DAGGER : QMG_MATVEC_RBJ_DAGGER);
         mg->add_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, 2 * invif.ops_count + 1, level);
         fine_storage->check_in(z3_prec);
       } else {
+        qmg::zero_guess_flag() = true;   // the iterate was zeroed just above: r0 = rhs, no A*0 (krylov.hpp)
         invif = minv_vector_minres(z3, r2, (int)fine_size_solve, n_post_smooth, post_smooth_tol, 0.85, apply_fine_M, (void*)fine_stencil);
         mg->add_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, invif.ops_count, level);
       }

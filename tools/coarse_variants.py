@@ -1,0 +1,35 @@
+"""A/B timing of the generic-nc (coarse) stencil kernel's tuning knobs at the K-cycle's coarse sizes, interleaved rounds
+in one process.  usage: coarse_variants.py L nc '[{"gen_sites":0},{"gen_sites":2}]'"""
+import importlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401  (before libqmg_hip)
+qmg = importlib.import_module("quantum-mg_amd")
+qmg.init(0)
+L = int(sys.argv[1]); nc = int(sys.argv[2])
+variants = json.loads(sys.argv[3])
+vol = L * L
+cl = qmg.DeviceArray(vol * nc * nc); qmg.gaussian(cl, vol * nc * nc, 1)
+ho = qmg.DeviceArray(4 * vol * nc * nc); qmg.gaussian(ho, 4 * vol * nc * nc, 2)
+x = qmg.DeviceArray(vol * nc); qmg.gaussian(x, vol * nc, 3)
+y = qmg.DeviceArray(vol * nc)
+d = qmg.make_desc(L, L, nc, cl, ho, -0.07)
+alg = (5 * nc * nc + 2 * nc) * 16 * vol
+timer = qmg.Timer()
+res = {i: [] for i in range(len(variants))}
+ref = None
+for rnd in range(6):
+    for i, v in enumerate(variants):
+        for k, val in v.items(): qmg.set_tuning(k, val)
+        for _ in range(3): qmg.stencil_apply(d, y, x, qmg.P_ALL | qmg.P_ZERO)
+        qmg.sync(); timer.start()
+        for _ in range(20): qmg.stencil_apply(d, y, x, qmg.P_ALL | qmg.P_ZERO)
+        res[i].append(timer.stop_ms() / 20)
+        if rnd == 0:
+            h = y.to_host()
+            if ref is None: ref = h
+            else: assert np.linalg.norm(h - ref) <= 1e-13 * np.linalg.norm(ref), "variant changed the result"
+for i, v in enumerate(variants):
+    t = np.array(res[i])
+    print("%-40s median %.4f ms min %.4f ms -> %.0f GB/s (median)" % (json.dumps(v), np.median(t), t.min(), alg / np.median(t) / 1e6))

@@ -1,0 +1,52 @@
+"""Split a rocprofv3 --kernel-trace of a K-cycle driver (n13/n19) into setup and solve and summarise the SOLVE phase:
+per-kernel totals, GPU busy time vs wall time (the gap is launch / host-sync latency), and launches per outer iteration.
+
+The solve starts after the last setup-only kernel (Galerkin probes / block-orthonormalisation leaves).  The full
+trace is too large to carry back from the GPU box, so this runs there and writes a small JSON:
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_n13 -- quantum-mg_amd/drivers/n13_wilson_kcycle ...
+    python tools/solve_phase_profile.py gpurun_out/prof_n13 > gpurun_out/n13_solve_phase.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+f = sorted(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
+SETUP_ONLY = ("k_probe_scatter", "k_unit_probe", "k_chol_store", "k_gaussian", "k_inv_real_sqrt")
+rows = []
+with open(f) as fh:
+    for r in csv.DictReader(fh):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+last_setup = max((i for i, r in enumerate(rows) if any(k in r[2] for k in SETUP_ONLY)), default=-1)
+solve = rows[last_setup + 1:]
+
+
+def summarise(rs):
+    if not rs:
+        return {}
+    wall = rs[-1][1] - rs[0][0]
+    busy = 0
+    cur_end = rs[0][0]
+    for s, e, _ in rs:   # union of intervals (kernels on one stream rarely overlap, but be exact)
+        if e > cur_end:
+            busy += e - max(s, cur_end)
+            cur_end = e
+    per = defaultdict(lambda: [0, 0])
+    for s, e, n in rs:
+        key = n.split("(")[0].replace("void qmg::", "").replace("qmg::", "")
+        per[key][0] += 1
+        per[key][1] += e - s
+    top = sorted(per.items(), key=lambda kv: -kv[1][1])
+    return {"wall_ms": wall / 1e6, "gpu_busy_ms": busy / 1e6, "idle_frac": 1.0 - busy / wall, "launches": len(rs),
+            "avg_gap_us": (wall - busy) / 1e3 / max(1, len(rs) - 1),
+            "kernels": [{"kernel": k, "calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3, "pct_of_wall": 100.0 * v[1] / wall} for k, v in top[:16]]}
+
+
+out = {"trace": os.path.basename(f), "setup": summarise(rows[:last_setup + 1]), "solve": summarise(solve)}
+# the driver's tail (true-residual check, dumps) is a handful of launches and stays inside "solve"
+print(json.dumps(out, indent=1))
