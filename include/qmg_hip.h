@@ -114,6 +114,11 @@ int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, in
  * other (the reference's in-place use, stencil_2d.h:1904, staggered.h:236). */
 int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                       int nrhs, size_t vec_stride, void* stream);
+/* Same, for a lock-step batch of at most 16 systems of which only those with their bit set in `mask` are read or
+ * written.  With nc in {8,12,16,24,32} and two or more active systems the apply runs as an (nc x nc).(nc x k)
+ * contraction on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the matrices read once for all k. */
+int qmg_stencil_apply_batch(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                            int nrhs, size_t vec_stride, unsigned mask, void* stream);
 
 /* ---------------- operator construction from U(1) links (device side) ---------------- */
 /* gauge: nc=1 LatticeGauge (mu,eo,y,x), 2*Lx*Ly complex. */
@@ -187,6 +192,30 @@ int qmg_block_bi_orthonormalize(void* prolong_vecs, void* restrict_vecs, int nve
 int qmg_coarse_build(void* coarse_clover, void* coarse_hopping, const qmg_stencil_desc* fine,
                      const void* nullvecs, const void* restrict_vecs /* or NULL */,
                      int cLx, int cLy, int cnc, void* stream);
+
+/* ---------------- lock-step batches of independent right-hand sides ---------------- */
+/* A batch vector is nrhs <= 16 vectors of n complex at a common `stride` (complex elements).  `mask` selects the
+ * ACTIVE systems; a frozen system is neither read nor written.  Per-system arithmetic (including the reduction
+ * order) is that of the single-vector entry points above.  Scalars are per system: a[2k], a[2k+1] = re, im. */
+typedef enum { QMG_BOP_ZERO = 0, QMG_BOP_COPY = 1, QMG_BOP_CAX = 2, QMG_BOP_CAXPY = 3, QMG_BOP_CXPY = 4, QMG_BOP_CAXPBYZ = 5 } qmg_batch_op;
+/* ZERO: z = 0; COPY: z = x; CAX: z *= a; CAXPY: z += a x; CXPY: z += x; CAXPBYZ: z = a x + b y */
+int qmg_batch_blas(int op, const double* a, const double* b, const void* x, const void* y, void* z, size_t n,
+                   int nrhs, size_t stride, unsigned mask, void* stream);
+/* y_k += sum_j c[j][k] xs[j]_k ; coeffs[(j*nrhs + k)*2 + {0,1}]; xs: HOST array of nj batch base pointers */
+int qmg_batch_multi_caxpy(const double* coeffs, const void* const* xs, int nj, void* y, size_t n,
+                          int nrhs, size_t stride, unsigned mask, void* stream);
+typedef enum { QMG_BRED_NORM2 = 0, QMG_BRED_DOT = 1, QMG_BRED_DIFFNORM2 = 2 } qmg_batch_red;
+/* out_host[2k], out_host[2k+1] for each active system k; synchronises the stream */
+int qmg_batch_reduce(int op, const void* x, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
+                     double* out_host, void* stream);
+/* out_host[(k*nj + j)*2 + {0,1}] = <xs[j]_k, y_k>, nj <= 32; synchronises the stream */
+int qmg_batch_multidot(const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
+                       double* out_host, void* stream);
+/* transfer.h:455-511 for the batch: the nvec null vectors are read once per 8 active systems */
+int qmg_prolong_batch(const void* nullvecs, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc,
+                      int cLx, int cLy, int cnc, int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream);
+int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
+                       int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
 
 /* ---------------- multi-GPU: independent right-hand sides per rank ---------------- */
 /* The path shards over right-hand sides; every rank holds a replica of the stencil/transfer data and

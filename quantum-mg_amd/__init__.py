@@ -35,13 +35,14 @@ ABI_SYMBOLS = [
     "qmg_malloc", "qmg_free", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
     "qmg_stream_create", "qmg_stream_destroy", "qmg_stream_sync",
     "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms",
-    "qmg_cshift", "qmg_stencil_apply", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
+    "qmg_cshift", "qmg_stencil_apply", "qmg_stencil_apply_batch", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
     "qmg_build_dagger", "qmg_build_rbjacobi", "qmg_cmat_conjtrans",
     "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",
     "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
+    "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
 ]
 
@@ -324,6 +325,63 @@ def block_bi_orthonormalize(pvecs, rvecs, nvec, fdims, cLx, cLy, block_L=None, b
 
 def coarse_build(cclover, chopping, fdesc, nullvecs, cdims, restrict_vecs=None):
     check(lib().qmg_coarse_build(_vp(cclover), _vp(chopping), C.byref(fdesc), _vp(nullvecs), _vp(restrict_vecs), *cdims, None), "qmg_coarse_build")
+
+
+# ---------------- lock-step batches (qmg_batch.hip) ----------------
+BOP_ZERO, BOP_COPY, BOP_CAX, BOP_CAXPY, BOP_CXPY, BOP_CAXPBYZ = range(6)
+BRED_NORM2, BRED_DOT, BRED_DIFFNORM2 = range(3)
+
+
+def _coef(a, nrhs):
+    if a is None:
+        return None
+    v = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.complex128), (nrhs,))).view(np.float64)
+    return v.ctypes.data_as(C.POINTER(C.c_double)), v
+
+
+def stencil_apply_batch(desc, lhs, rhs, pieces, nrhs, vec_stride, mask, stream=None):
+    check(lib().qmg_stencil_apply_batch(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
+          "qmg_stencil_apply_batch")
+
+
+def batch_blas(op, z, n, nrhs, stride, mask, a=None, b=None, x=None, y=None):
+    ca, cb = _coef(a, nrhs), _coef(b, nrhs)
+    check(lib().qmg_batch_blas(op, ca[0] if ca else None, cb[0] if cb else None, _vp(x), _vp(y), _vp(z), C.c_size_t(n), nrhs, C.c_size_t(stride),
+                               C.c_uint(mask), None), "qmg_batch_blas")
+
+
+def batch_multi_caxpy(coeffs, xs, y, n, nrhs, stride, mask):
+    nj = len(xs)
+    cf = np.ascontiguousarray(np.asarray(coeffs, dtype=np.complex128).reshape(nj, nrhs)).view(np.float64)
+    ptrs = (C.c_void_p * nj)(*[x.ptr for x in xs])
+    check(lib().qmg_batch_multi_caxpy(cf.ctypes.data_as(C.POINTER(C.c_double)), ptrs, nj, _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None),
+          "qmg_batch_multi_caxpy")
+
+
+def batch_reduce(op, x, y, n, nrhs, stride, mask):
+    out = np.full(2 * nrhs, np.nan)
+    check(lib().qmg_batch_reduce(op, _vp(x), _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), out.ctypes.data_as(C.POINTER(C.c_double)), None),
+          "qmg_batch_reduce")
+    return out[0::2] + 1j * out[1::2]
+
+
+def batch_multidot(xs, y, n, nrhs, stride, mask):
+    nj = len(xs)
+    ptrs = (C.c_void_p * nj)(*[x.ptr for x in xs])
+    out = np.full(2 * nrhs * nj, np.nan)
+    check(lib().qmg_batch_multidot(ptrs, nj, _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), out.ctypes.data_as(C.POINTER(C.c_double)), None),
+          "qmg_batch_multidot")
+    return (out[0::2] + 1j * out[1::2]).reshape(nrhs, nj)
+
+
+def prolong_batch(nullvecs, nvec, coarse, fine, fdims, cdims, nrhs, cstride, fstride, mask):
+    check(lib().qmg_prolong_batch(_vp(nullvecs), nvec, _vp(coarse), _vp(fine), *fdims, *cdims, nrhs, C.c_size_t(cstride), C.c_size_t(fstride), C.c_uint(mask), None),
+          "qmg_prolong_batch")
+
+
+def restrict_batch(nullvecs, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
+    check(lib().qmg_restrict_batch(_vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
+          "qmg_restrict_batch")
 
 
 def set_tuning(key, value):

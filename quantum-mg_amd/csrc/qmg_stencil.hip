@@ -45,8 +45,12 @@ struct StencilArgs {
   int par_count;     // 1 or 2 (2: rows interleaved even/odd)
   int nrows;         // Ly * par_count
   double shift[2], eo_shift[2], dof_shift[2];
+  unsigned char ridx[16];   // masked batches (qmg_stencil_apply_batch): right-hand side processed as column k; else unused
+  int use_idx;       // 0: column k is right-hand side k
   int ablate;        // diagnostic builds only (tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 };
+
+__device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)(a.use_idx ? (int)a.ridx[k] : k) * a.vec_stride; }
 
 template <bool NT>
 __device__ __forceinline__ cplx ld(const cplx* p) {
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
     const bool need_own = do_clover || do_shift;
 
     for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + (long)k * a.vec_stride;
-      cplx* out = a.lhs + (long)k * a.vec_stride;
+      const cplx* x = a.rhs + rhs_offset(a, k);
+      cplx* out = a.lhs + rhs_offset(a, k);
       cplx xv[5];
 #pragma unroll
       for (int d = 0; d < 4; d++)
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
       }
 
     for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + (long)k * a.vec_stride;
-      cplx* out = a.lhs + (long)k * a.vec_stride;
+      const cplx* x = a.rhs + rhs_offset(a, k);
+      cplx* out = a.lhs + rhs_offset(a, k);
       const cplx* xe = x;                       // even half
       const cplx* xo = x + a.half_vol * NC;     // odd half
 
@@ -332,8 +336,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
     const int ym = (y == 0) ? a.Ly - 1 : y - 1;
 
     for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + (long)k * a.vec_stride;
-      cplx* out = a.lhs + (long)k * a.vec_stride;
+      const cplx* x = a.rhs + rhs_offset(a, k);
+      cplx* out = a.lhs + rhs_offset(a, k);
       cplx acc = cmake(0.0, 0.0);
 
       // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
@@ -416,10 +420,187 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel C (nc in {8,12,16,24,32}, 2..16 right-hand sides per pass): the coarse apply as a real contraction on the f64
+// matrix cores.  With k right-hand sides against one matrix read the per-site work is the (nc x nc) . (nc x k) product
+//     out[r][k] (+)= sum_piece sum_c M_piece(x)[r][c] * X_k(nb_piece(x))[c]
+// and the arithmetic intensity rises from 0.5 flop/B to ~0.5 k flop/B; 16 right-hand sides move 5 nc^2 + 32 nc complex
+// per site instead of 16 (5 nc^2 + 2 nc).  One wavefront owns one output site.  v_mfma_f64_16x16x4_f64 tiles:
+//     A (16 x 4)  = M[16 t + (lane&15)][4 s + (lane>>4)]       each lane's 16 B carries (re, im)
+//     B (4 x 16)  = X_{lane&15}[4 s + (lane>>4)]                one right-hand side per MFMA column
+//     C (16 x 16) : row = 16 t + 4 i + (lane>>4), column = lane&15 for accumulator register i      (f64 C/D map)
+// A complex MAC is four real MFMAs (re += ar.br - ai.bi ; im += ar.bi + ai.br).  Rows / k-steps beyond nc and columns
+// beyond the rhs count are fed zeros.
+// Matrix stream: a site's piece is nc^2 contiguous complex; the wavefront reads it with fully coalesced non-temporal
+// 1-KiB loads (lane-linear), parks it in its own LDS slice with odd row stride nc+1 (conflict-free operand reads), and
+// pulls A fragments from there.  Operand-layout loads straight from HBM touch half a cache line per 4 lanes and ran at
+// 4.5 TB/s with the MFMAs removed; the staged stream is what the 5.8 TB/s single-rhs kernels use.  The slice is private
+// to the wavefront, so the write->read hand-off is a wavefront fence, not a block barrier; the global loads of piece
+// p+2 are in flight while piece p+1 computes.  The own-site vector in B layout IS the shift term's operand in C layout
+// (k-step s = 4 t + i holds row 16 t + 4 i + (lane>>4)); it is re-read from L2 in the epilogue.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// MODE 0: four real MFMAs per complex tile product (plain).
+// MODE 1: at most 8 right-hand sides: columns 0-7 carry Re X_k, columns 8-15 Im X_k, so P = Re(M).[Xr|Xi] and
+//         Q = Im(M).[Xr|Xi] are TWO MFMAs per tile product; the epilogue recombines re_k = P[k] - Q[k+8],
+//         im_k = P[k+8] + Q[k] with one lane exchange (lane ^ 8).
+// (A three-multiplication complex product for 9-16 right-hand sides was measured SLOWER than MODE 0 -- 4.09 vs 3.63 ms
+// at 512^2, nc = 24, 16 rhs: the extra f64 adds and the third accumulator cost more than the saved MFMA -- and dropped.)
+// The f64 matrix pipe sustains 48 TFLOP/s on this part (tools/mfma_f64_rate.hip), which at nc = 24 is 2.7 ms of plain
+// MFMA work per 512^2 apply against 2.4 ms of HBM time -- the MFMA count, not the byte count, is what MODE 1 cuts.
+template <int NC, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, const int nk) {
+  constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
+  constexpr int NACC = 2;
+  constexpr int RS = NC + 1;                      // LDS row stride (complex), odd
+  constexpr int NC2 = NC * NC;
+  constexpr int NG = (NC2 + WAVE - 1) / WAVE;     // staged 16-B elements per lane per piece
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+  cplx* mlds = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * NC * RS;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int j = blockIdx.x * (BLOCK / WAVE) + wave;
+  if (j >= a.hr) return;                      // whole wavefront leaves; the kernel has no block barriers
+  const int kcol = (MODE == 1) ? (lr & 7) : lr;   // right-hand side this lane's MFMA column belongs to
+  const bool kval = kcol < nk;                 // ... and whether it exists
+  const long koff = rhs_offset(a, kcol & 15);
+
+  for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
+    const int y = (a.par_count == 2) ? (row >> 1) : row;
+    const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
+    const unsigned hop_mask = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
+    const bool do_shift = (a.pieces >> (10 + p)) & 1u;
+    const bool do_zero = (a.pieces >> (12 + p)) & 1u;
+
+    const long site = (long)p * a.half_vol + (long)y * a.hr + j;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const int s = (y + p) & 1;
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
+    const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+    int jp = j + s; if (jp == a.hr) jp = 0;
+    int jm = j + s - 1; if (jm < 0) jm = a.hr - 1;
+    // piece slots in the reference's accumulation order: clover, +x, +y, -x, -y
+    const long nb[5] = {site, opp + (long)y * a.hr + jp, opp + (long)yp * a.hr + j, opp + (long)y * a.hr + jm, opp + (long)ym * a.hr + j};
+    const bool act[5] = {do_clover, (bool)(hop_mask & 1u), (bool)(hop_mask & 2u), (bool)(hop_mask & 4u), (bool)(hop_mask & 8u)};
+
+    v4d acc[NACC][RT];   // MODE 0: (re, im); MODE 1: (P, Q)
+#pragma unroll
+    for (int n = 0; n < NACC; n++)
+#pragma unroll
+      for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    cplx G[NG], B[2][KS];
+    auto load_piece = [&](int pc, int set) {      // global -> registers: matrix (lane-linear) and the k right-hand sides
+      const cplx* m = ((pc == 0) ? a.clover : a.hopping + (long)(pc - 1) * a.size_cm) + site * NC2;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int el = g * WAVE + lane;
+        G[g] = (NC2 % WAVE == 0 || el < NC2) ? ld<true>(m + el) : cmake(0.0, 0.0);
+      }
+      const cplx* x = a.rhs + koff + nb[pc] * NC;
+#pragma unroll
+      for (int q = 0; q < KS; q++) {
+        const int c = 4 * q + lq;
+        B[set][q] = (kval && c < NC) ? x[c] : cmake(0.0, 0.0);
+      }
+    };
+    auto park_piece = [&]() {                     // registers -> this wavefront's LDS slice, padded rows
+      wave_lds_handoff();                         // the previous piece's fragment reads are done
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int el = g * WAVE + lane;
+        if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[g];
+      }
+      wave_lds_handoff();
+    };
+    auto mac_piece = [&](int set) {
+#pragma unroll
+      for (int q = 0; q < KS; q++) {
+        cplx Af[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+          const int r = 16 * t + lr, c = 4 * q + lq;
+          Af[t] = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds[r * RS + c] : cmake(0.0, 0.0);
+        }
+        if (a.ablate & 8) {   // diagnostic: operands kept alive by one vector FMA each, no matrix-core work
+#pragma unroll
+          for (int t = 0; t < RT; t++) { acc[0][t][0] = fma(Af[t].x, B[set][q].x, acc[0][t][0]); acc[1][t][0] = fma(Af[t].y, B[set][q].y, acc[1][t][0]); }
+          continue;
+        }
+        if (MODE == 0) {
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q].x, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q].y, acc[1][t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Af[t].y, B[set][q].y, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q].x, acc[1][t], 0, 0, 0);
+          }
+        } else {
+          const double bp = (lr < 8) ? B[set][q].x : B[set][q].y;
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, bp, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, bp, acc[1][t], 0, 0, 0);
+          }
+        }
+      }
+    };
+
+    // software pipeline over the five piece slots (activity is uniform over the block).  Slot pc+1 is prefetched while
+    // slot pc computes; a slot whose predecessor is inactive loads on demand.  All register-set indices are
+    // compile-time constants after unrolling.
+    if (act[0]) load_piece(0, 0);
+#pragma unroll
+    for (int pc = 0; pc < 5; pc++) {
+      if (!act[pc]) continue;
+      if (pc > 0 && !act[pc - 1]) load_piece(pc, pc & 1);
+      park_piece();                               // G held piece pc; it is free again after this
+      if (pc + 1 < 5 && act[pc + 1]) load_piece(pc + 1, (pc + 1) & 1);
+      mac_piece(pc & 1);
+    }
+
+    // epilogue: shift, accumulate, store.  Lane (lq, lr) owns rows 16 t + 4 i + lq of right-hand side lr.
+    const double sg = p ? -1.0 : 1.0;
+#pragma unroll
+    for (int t = 0; t < RT; t++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int r = 16 * t + 4 * i + lq;
+        cplx v;
+        if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
+        else {   // partner lane (lr ^ 8) holds the other half of the packed columns
+          const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
+          v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+        }
+        if (r < NC && kval && (MODE != 1 || lr < 8)) {
+          const long o = koff + site * NC + r;
+          if (do_shift) {
+            const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+            const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+            cmac(v, sh, a.rhs[o]);
+          }
+          if (!do_zero) v = cadd(a.lhs[o], v);
+          a.lhs[o] = v;
+        }
+      }
+    }
+  }
+}
+
 static int g_stencil_nt = 3;     // tuning knob: bit0 non-temporal matrix loads, bit1 non-temporal stores (kernel A)
 static int g_stencil_ablate = 0;
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
+static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
 static GenLayout make_gen_layout(int nc, int hr) {
@@ -452,11 +633,34 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 
+static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
+                              const unsigned char* ridx, void* stream);
+
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
+  return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream);
+}
+
+// Masked batch: only the right-hand sides whose bit is set in `mask` are read or written (a lock-step batched solver
+// freezes the systems that have converged).  At most 16 right-hand sides per call.
+extern "C" int qmg_stencil_apply_batch(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                                       int nrhs, size_t vec_stride, unsigned mask, void* stream) {
+  if (nrhs < 1 || nrhs > 16) return QMG_ERR_INVALID;
+  unsigned char ridx[16];
+  int n = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
+  if (n == 0) return QMG_SUCCESS;
+  if (n == nrhs) return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream);
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream);
+}
+
+static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
+                              const unsigned char* ridx, void* stream) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -474,6 +678,8 @@ extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const voi
   a.pieces = pieces;
   a.nrhs = nrhs;
   a.vec_stride = (long)vec_stride;
+  a.use_idx = ridx ? 1 : 0;
+  for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
   a.ablate = g_stencil_ablate;
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
 
@@ -527,6 +733,37 @@ extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const voi
     if (nc == 2) { QMG_ELEM_LAUNCH(2) }
     if (nc == 4) { QMG_ELEM_LAUNCH(4) }
 #undef QMG_ELEM_LAUNCH
+    QMG_LAUNCH_CHECK();
+    return QMG_SUCCESS;
+  }
+
+  if (a.nrhs > 1 && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
+    // kernel C: up to 16 right-hand sides per pass share one read of the matrices
+    const unsigned gx = (unsigned)((a.hr + BLOCK / WAVE - 1) / (BLOCK / WAVE));
+    dim3 grid(gx, gy), block(BLOCK);
+    for (int k0 = 0; k0 < a.nrhs; k0 += 16) {
+      StencilArgs b = a;
+      b.lhs = a.lhs + (long)k0 * a.vec_stride;
+      b.rhs = a.rhs + (long)k0 * a.vec_stride;
+      const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
+      const size_t smem = sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
+      const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
+#define QMG_MFMA_LAUNCH(NC)                                                                                     \
+      if (smem > 64 * 1024) {                                                                                   \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      }                                                                                                         \
+      if (mode == 0) k_stencil_mfma<NC, 0><<<grid, block, smem, st>>>(b, nk);                                   \
+      else k_stencil_mfma<NC, 1><<<grid, block, smem, st>>>(b, nk);
+      switch (nc) {
+        case 8: QMG_MFMA_LAUNCH(8) break;
+        case 12: QMG_MFMA_LAUNCH(12) break;
+        case 16: QMG_MFMA_LAUNCH(16) break;
+        case 24: QMG_MFMA_LAUNCH(24) break;
+        default: QMG_MFMA_LAUNCH(32) break;
+      }
+#undef QMG_MFMA_LAUNCH
+    }
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }

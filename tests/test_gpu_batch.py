@@ -1,0 +1,175 @@
+"""Lock-step batches (qmg_batch.hip, qmg_stencil_apply_batch): every batched entry point against the single-vector
+entry point applied per active system -- bit-identical for element-wise ops and reductions (same block partition and
+fixed-order second stage), 1e-13 for the MFMA / register-blocked kernels whose summation order differs -- and frozen
+(masked-out) systems must come back untouched."""
+import importlib
+
+import numpy as np
+import pytest
+
+import coordspace as cs
+import oracle_lib as ol
+
+qmg = importlib.import_module("quantum-mg_amd")
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    qmg.build()
+    qmg.init(0)
+    yield
+    qmg.sync()
+
+
+def D(a):
+    return qmg.DeviceArray.from_host(np.ascontiguousarray(a, dtype=np.complex128))
+
+
+def active(mask, nrhs):
+    return [k for k in range(nrhs) if (mask >> k) & 1]
+
+
+MASKS = [(5, 0b11111), (5, 0b01101), (16, 0xFFFF), (16, 0x8421), (3, 0b010), (9, 0b111111111)]
+
+
+@pytest.mark.parametrize("nrhs,mask", MASKS)
+def test_batch_blas_bit_identical_and_masked(nrhs, mask):
+    n, pad = 1000, 7
+    stride = n + pad
+    x = cs.gaussian_cvec(stride * nrhs, 1)
+    y = cs.gaussian_cvec(stride * nrhs, 2)
+    z0 = cs.gaussian_cvec(stride * nrhs, 3)
+    a = cs.gaussian_cvec(nrhs, 4)
+    b = cs.gaussian_cvec(nrhs, 5)
+    dx, dy = D(x), D(y)
+    single = {qmg.BOP_ZERO: lambda zk, xk, yk, k: qmg.zero_vector(zk, n), qmg.BOP_COPY: lambda zk, xk, yk, k: qmg.copy_vector(zk, xk, n),
+              qmg.BOP_CAX: lambda zk, xk, yk, k: qmg.cax(a[k], zk, n), qmg.BOP_CAXPY: lambda zk, xk, yk, k: qmg.caxpy(a[k], xk, zk, n),
+              qmg.BOP_CXPY: lambda zk, xk, yk, k: qmg.cxpy(xk, zk, n), qmg.BOP_CAXPBYZ: lambda zk, xk, yk, k: qmg.caxpbyz(a[k], xk, b[k], yk, zk, n)}
+    for op, fn in single.items():
+        dz = D(z0)
+        qmg.batch_blas(op, dz, n, nrhs, stride, mask, a=a, b=b, x=dx, y=dy)
+        got = dz.to_host()
+        want = z0.copy()
+        for k in active(mask, nrhs):
+            zk, xk, yk = D(z0[k * stride:k * stride + n]), D(x[k * stride:k * stride + n]), D(y[k * stride:k * stride + n])
+            fn(zk, xk, yk, k)
+            want[k * stride:k * stride + n] = zk.to_host()
+        assert np.array_equal(got, want), op
+
+
+@pytest.mark.parametrize("nrhs,mask", MASKS)
+@pytest.mark.parametrize("n", [1, 777, 300001])
+def test_batch_reductions_bit_identical(nrhs, mask, n):
+    stride = n + 3
+    x = cs.gaussian_cvec(stride * nrhs, 11)
+    y = cs.gaussian_cvec(stride * nrhs, 12)
+    dx, dy = D(x), D(y)
+    nrm = qmg.batch_reduce(qmg.BRED_NORM2, dx, None, n, nrhs, stride, mask)
+    dt = qmg.batch_reduce(qmg.BRED_DOT, dx, dy, n, nrhs, stride, mask)
+    df = qmg.batch_reduce(qmg.BRED_DIFFNORM2, dx, dy, n, nrhs, stride, mask)
+    for k in range(nrhs):
+        if (mask >> k) & 1:
+            xk, yk = D(x[k * stride:k * stride + n]), D(y[k * stride:k * stride + n])
+            assert nrm[k].real == qmg.norm2sq(xk, n)
+            assert dt[k] == qmg.dot(xk, yk, n)
+            assert df[k].real == qmg.diffnorm2sq(xk, yk, n)
+            assert abs(dt[k] - np.vdot(x[k * stride:k * stride + n], y[k * stride:k * stride + n])) <= 1e-12 * abs(dt[k]) + 1e-12
+        else:
+            assert np.isnan(nrm[k].real) and np.isnan(dt[k].real)   # untouched
+
+
+@pytest.mark.parametrize("nj", [1, 2, 5, 11, 32])
+def test_batch_multidot_and_multi_caxpy(nj):
+    nrhs, mask, n = 6, 0b101101, 4099
+    stride = n + 5
+    xs = [cs.gaussian_cvec(stride * nrhs, 20 + j) for j in range(nj)]
+    y = cs.gaussian_cvec(stride * nrhs, 99)
+    dxs, dy = [D(v) for v in xs], D(y)
+    got = qmg.batch_multidot(dxs, dy, n, nrhs, stride, mask)
+    for k in range(nrhs):
+        if (mask >> k) & 1:
+            single = qmg.multidot([D(v[k * stride:k * stride + n]) for v in xs], D(y[k * stride:k * stride + n]), n)
+            assert np.array_equal(got[k], single)
+        else:
+            assert np.all(np.isnan(got[k].real))
+    coeffs = cs.gaussian_cvec(nj * nrhs, 7).reshape(nj, nrhs)
+    qmg.batch_multi_caxpy(coeffs, dxs, dy, n, nrhs, stride, mask)
+    out = dy.to_host()
+    want = y.copy()
+    for k in active(mask, nrhs):
+        sl = slice(k * stride, k * stride + n)
+        for j in range(nj):
+            want[sl] += coeffs[j, k] * xs[j][sl]
+    assert np.array_equal(out[[i for k in range(nrhs) if not (mask >> k) & 1 for i in range(k * stride, (k + 1) * stride)]],
+                          y[[i for k in range(nrhs) if not (mask >> k) & 1 for i in range(k * stride, (k + 1) * stride)]])
+    assert cs.rel_l2(out, want) < TOL
+
+
+@pytest.mark.parametrize("nc,nrhs,mask", [(2, 4, 0b1011), (1, 3, 0b101), (8, 6, 0b110101), (24, 16, 0xFFFF), (24, 12, 0b101010111011), (3, 4, 0b0110), (16, 2, 0b10)])
+def test_stencil_apply_batch_masked(nc, nrhs, mask):
+    Lx, Ly = 12, 6
+    vol = Lx * Ly
+    size = vol * nc
+    stride = size + 4
+    clover = cs.gaussian_cvec(vol * nc * nc, 1)
+    hopping = cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    rhs = cs.gaussian_cvec(stride * nrhs, 3)
+    lhs0 = cs.gaussian_cvec(stride * nrhs, 4)
+    shifts = (0.3 - 0.2j, 0.11, -0.07 + 0.02j)
+    od = ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts)
+    gd = qmg.make_desc(Lx, Ly, nc, D(clover), D(hopping), *shifts)
+    for pieces in (ol.P_ALL | ol.P_ZERO, ol.P_ALL, ol.P_EO | ol.P_ZERO_E):
+        want = lhs0.copy()
+        for k in active(mask, nrhs):
+            ol.stencil_apply(od, np.ascontiguousarray(rhs[k * stride:k * stride + size]), pieces, lhs=want[k * stride:k * stride + size])
+        dl = D(lhs0)
+        qmg.stencil_apply_batch(gd, dl, D(rhs), pieces, nrhs, stride, mask)
+        got = dl.to_host()
+        assert cs.rel_l2(got, want) < TOL
+        for k in range(nrhs):
+            if not (mask >> k) & 1:
+                assert np.array_equal(got[k * stride:(k + 1) * stride], lhs0[k * stride:(k + 1) * stride])
+
+
+@pytest.mark.parametrize("fd,cd,nrhs,mask", [((16, 16, 2), (4, 4, 8), 5, 0b10111), ((16, 8, 2), (8, 4, 4), 9, 0b110110101), ((8, 8, 8), (2, 2, 12), 16, 0xFFFF),
+                                             ((16, 16, 24), (4, 4, 24), 3, 0b101), ((32, 32, 2), (8, 8, 24), 8, 0xFF), ((8, 8, 6), (4, 4, 6), 2, 0b11)])
+def test_transfer_batch_matches_single(fd, cd, nrhs, mask):
+    fsize, csize = fd[0] * fd[1] * fd[2], cd[0] * cd[1] * cd[2]
+    nvec = cd[2]
+    fstride, cstride = fsize + 6, csize + 2
+    nv = cs.gaussian_cvec(nvec * fsize, 1)
+    fine0 = cs.gaussian_cvec(fstride * nrhs, 2)
+    coarse0 = cs.gaussian_cvec(cstride * nrhs, 3)
+    dnv = D(nv)
+    # prolong: fine += P coarse
+    df = D(fine0)
+    qmg.prolong_batch(dnv, nvec, D(coarse0), df, fd, cd, nrhs, cstride, fstride, mask)
+    got = df.to_host()
+    want = fine0.copy()
+    for k in active(mask, nrhs):
+        fk = D(fine0[k * fstride:k * fstride + fsize])
+        qmg.prolong(dnv, nvec, D(coarse0[k * cstride:k * cstride + csize]), fk, fd, cd)
+        want[k * fstride:k * fstride + fsize] = fk.to_host()
+    assert cs.rel_l2(got, want) < TOL
+    for k in range(nrhs):
+        if not (mask >> k) & 1:
+            assert np.array_equal(got[k * fstride:(k + 1) * fstride], fine0[k * fstride:(k + 1) * fstride])
+    # and against the oracle for the first active system
+    k = active(mask, nrhs)[0]
+    o = ol.prolong(nv, coarse0[k * cstride:k * cstride + csize].copy(), fd, cd, fine=fine0[k * fstride:k * fstride + fsize].copy())
+    assert cs.rel_l2(got[k * fstride:k * fstride + fsize], o) < TOL
+    # restrict: coarse += R fine
+    dc = D(coarse0)
+    qmg.restrict_batch(dnv, nvec, D(fine0), dc, fd, cd, nrhs, fstride, cstride, mask)
+    got = dc.to_host()
+    want = coarse0.copy()
+    for k in active(mask, nrhs):
+        ck = D(coarse0[k * cstride:k * cstride + csize])
+        qmg.restrict(dnv, nvec, D(fine0[k * fstride:k * fstride + fsize]), ck, fd, cd)
+        want[k * cstride:k * cstride + csize] = ck.to_host()
+    assert cs.rel_l2(got, want) < TOL
+    for k in range(nrhs):
+        if not (mask >> k) & 1:
+            assert np.array_equal(got[k * cstride:(k + 1) * cstride], coarse0[k * cstride:(k + 1) * cstride])

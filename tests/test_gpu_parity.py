@@ -247,6 +247,38 @@ def test_multi_rhs_shares_matrices(nc):
     assert cs.rel_l2(got, want) < TOL
 
 
+@pytest.mark.parametrize("nc,nrhs", [(8, 2), (8, 16), (12, 5), (16, 16), (24, 8), (24, 19), (32, 3)])
+def test_multi_rhs_coarse_apply_on_matrix_cores(nc, nrhs):
+    """Kernel C (v_mfma_f64_16x16x4_f64): every piece subset the facade launches, all three shifts, overwrite and
+    accumulate, ragged rhs counts (19 = one full pass of 16 + 3), against the oracle applied per right-hand side."""
+    Lx, Ly = 12, 6
+    vol = Lx * Ly
+    clover = cs.gaussian_cvec(vol * nc * nc, 1)
+    hopping = cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    rhs = cs.gaussian_cvec(vol * nc * nrhs, 3)
+    lhs0 = cs.gaussian_cvec(vol * nc * nrhs, 4)
+    shifts = (0.3 - 0.2j, 0.11 + 0.05j, -0.07 + 0.02j)
+    for pieces, l0 in ((ol.P_ALL | ol.P_ZERO, None), (ol.P_ALL, lhs0), (ol.P_EO | ol.P_ZERO_E, lhs0), (ol.P_OE, lhs0),
+                       (ol.P_CLOVER | ol.P_SHIFT | ol.P_ZERO, None), (ol.P_HOPPING | ol.P_SHIFT | ol.P_ZERO, None), (ol.P_EO_XP1 | (ol.P_OE_XP1 << 3), lhs0)):   # +x into even, -y into odd
+        want, got = _apply_both(Lx, Ly, nc, clover, hopping, rhs, pieces, shifts, lhs0=l0, nrhs=nrhs)
+        assert cs.rel_l2(got, want) < TOL, hex(pieces)
+    # and it is the same operator as the one-rhs-at-a-time kernel B
+    qmg.set_tuning("stencil_mfma", 0)
+    try:
+        _, got_b = _apply_both(Lx, Ly, nc, clover, hopping, rhs, ol.P_ALL | ol.P_ZERO, shifts, nrhs=nrhs)
+    finally:
+        qmg.set_tuning("stencil_mfma", 1)
+    _, got_c = _apply_both(Lx, Ly, nc, clover, hopping, rhs, ol.P_ALL | ol.P_ZERO, shifts, nrhs=nrhs)
+    assert cs.rel_l2(got_c, got_b) < TOL
+    # default mode (packed re|im columns for <= 8 rhs) vs the plain four-MFMA product
+    qmg.set_tuning("stencil_mfma", 2)
+    try:
+        _, got_plain = _apply_both(Lx, Ly, nc, clover, hopping, rhs, ol.P_ALL | ol.P_ZERO, shifts, nrhs=nrhs)
+    finally:
+        qmg.set_tuning("stencil_mfma", 1)
+    assert cs.rel_l2(got_plain, got_b) < TOL and cs.rel_l2(got_c, got_plain) < TOL
+
+
 @pytest.mark.parametrize("nc", [1, 2, 8])
 def test_in_place_eo_like_the_reference_schur(nc):
     """apply_M_rbjacobi_eo(eo_cvector, eo_cvector): reads the odd half, accumulates into the even half
