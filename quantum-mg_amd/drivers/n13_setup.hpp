@@ -1,0 +1,163 @@
+// n13_setup.hpp -- argument parsing and multigrid setup shared by n13_wilson_kcycle and n13_wilson_kcycle_mrhs
+// (tests/n13_wilson_kcycle/wilson_kcycle.cpp:86-372 restated on the device facade; see n13_wilson_kcycle.cpp).
+#ifndef N13_SETUP_HPP
+#define N13_SETUP_HPP
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../include/qmg/qmg.hpp"
+
+using namespace std;
+
+struct N13 {
+  int x_len, y_len, n_refine, coarse_dof;
+  double mass, tol;
+  int max_iter, restart_freq;
+  bool quiet;
+  const char* dump_dir;
+  unsigned long long seed;
+  double setup_s;
+  inversion_verbose_struct verb;
+  Lattice2D** lats;
+  Wilson2D* wilson_op;
+  StatefulMultigridMG* mg_object;
+  TransferMG** transfer_objs;
+  StatefulMultigridMG::LevelSolveMG** level_solve_objs;
+  StatefulMultigridMG::CoarsestSolveMG* coarsest_solve_obj;
+  complex<double>* gauge_field;
+
+  // returns 0 on success (the reference's exit codes otherwise)
+  int build(int argc, char** argv);
+  void print_ops_stats() {
+    cout << setprecision(6);
+    for (int i = 0; i <= n_refine; i++)
+      cout << "[QMG-OPS-STATS]: Level " << i << " NullVec " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_NULLVEC, i) << " PreSmooth "
+           << mg_object->get_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, i) << " Krylov " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_KRYLOV, i)
+           << " PostSmooth " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, i) << " Total " << mg_object->get_total_count(i) << "\n";
+  }
+  void destroy() {
+    delete mg_object;
+    for (int i = 0; i < n_refine; i++) { delete transfer_objs[i]; delete level_solve_objs[i]; }
+    delete[] transfer_objs; delete[] level_solve_objs; delete coarsest_solve_obj;
+    delete wilson_op;
+    for (int i = 0; i <= n_refine; i++) delete lats[i];
+    delete[] lats;
+    deallocate_vector(&gauge_field);
+    qmg::VecPool::release_all();
+  }
+};
+
+inline int N13::build(int argc, char** argv) {
+  if (argc < 5) {
+    std::cout << "Error: ./wilson_kcycle expects four arguments, L, mass, beta, n_refine. Try mass = -0.075 for beta 6.0.\n";
+    return -1;
+  }
+  cout << setprecision(20);
+  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  x_len = stoi(argv[1]); y_len = stoi(argv[1]);
+  mass = stod(argv[2]);
+  const double beta = stod(argv[3]);
+  (void)beta;
+  n_refine = stoi(argv[4]);
+  coarse_dof = (argc > 5) ? stoi(argv[5]) : 8;
+  const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
+  const int tile = (argc > 7) ? stoi(argv[7]) : 64;
+  quiet = getenv("QMG_QUIET") != 0;
+  dump_dir = getenv("QMG_DUMP_DIR");   // test hook: null vectors, rhs and solution as raw complex128
+  const int dof = Wilson2D::get_dof();
+  const int x_block = 4, y_block = 4;
+  tol = 1e-10; max_iter = 1000; restart_freq = 32;
+  const double inner_tol = 0.2; const int inner_max_iter = 1000; const int inner_restart_freq = 32;
+  const int n_pre_smooth = 2; const double pre_smooth_tol = 1e-15;
+  const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
+  const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
+  seed = 1337ull;
+
+  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verb_prefix = "Level 0: ";
+  verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.precond_verb_prefix = "Prec ";
+  inversion_verbose_struct verb_null(VERB_NONE, "");
+
+  lats = new Lattice2D*[n_refine + 1];
+  lats[0] = new Lattice2D(x_len, y_len, dof);
+  Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
+  gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
+  bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
+  if (!got) return 3;
+  delete lat_gauge;
+
+  auto t_setup0 = std::chrono::steady_clock::now();
+  wilson_op = new Wilson2D(lats[0], mass, gauge_field);
+  level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
+  coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
+  coarsest_solve_obj->coarsest_stencil_app = QMG_MATVEC_ORIGINAL;
+  coarsest_solve_obj->coarsest_tol = coarsest_tol;
+  coarsest_solve_obj->coarsest_iters = coarsest_max_iter;
+  coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
+  mg_object = new StatefulMultigridMG(lats[0], wilson_op, coarsest_solve_obj);
+
+  int curr_x_len = x_len, curr_y_len = y_len;
+  transfer_objs = new TransferMG*[n_refine];
+  for (int i = 1; i <= n_refine; i++) {
+    curr_x_len /= x_block; curr_y_len /= y_block;
+    lats[i] = new Lattice2D(curr_x_len, curr_y_len, coarse_dof);
+    const long fsize = lats[i - 1]->get_size_cv_l();
+    complex<double>** null_vectors = new complex<double>*[coarse_dof];
+    for (int j = 0; j < coarse_dof; j++) { null_vectors[j] = allocate_vector<complex<double>>(fsize); zero_vector(null_vectors[j], fsize); }
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
+      gaussian(rand_guess, fsize, seed++);
+      for (int k = 0; k < j; k++) orthogonal(rand_guess, null_vectors[k], fsize);
+      complex<double>* Arand_guess = mg_object->get_storage(i - 1)->check_out();
+      zero_vector(Arand_guess, fsize);
+      mg_object->get_stencil(i - 1)->apply_M(Arand_guess, rand_guess);
+      cax(-1.0, Arand_guess, fsize);
+      minv_vector_bicgstab_l(null_vectors[j], Arand_guess, (int)fsize, 500, 5e-5, 6, apply_stencil_2D_M, (void*)mg_object->get_stencil(i - 1), &verb_null);
+      cxpy(rand_guess, null_vectors[j], fsize);
+      mg_object->get_storage(i - 1)->check_in(rand_guess);
+      mg_object->get_storage(i - 1)->check_in(Arand_guess);
+      for (int k = 0; k < j; k++) orthogonal(null_vectors[j], null_vectors[k], fsize);
+    }
+    for (int j = 0; j < coarse_dof / 2; j++) {
+      mg_object->get_stencil(i - 1)->chiral_projection_both(null_vectors[j], null_vectors[j + lats[i]->get_nc() / 2]);
+      normalize(null_vectors[j], fsize);
+      normalize(null_vectors[j + lats[i]->get_nc() / 2], fsize);
+    }
+    if (dump_dir) {   // raw complex128, coarse_dof vectors back to back (pre block-ortho), for the parity test
+      std::string path = std::string(dump_dir) + "/nullvecs_level" + std::to_string(i - 1) + ".bin";
+      FILE* f = fopen(path.c_str(), "wb");
+      for (int j = 0; j < coarse_dof; j++) {
+        std::vector<complex<double>> h = qmg::to_host(null_vectors[j], (size_t)fsize);
+        fwrite(h.data(), sizeof(complex<double>), h.size(), f);
+      }
+      fclose(f);
+    }
+    transfer_objs[i - 1] = new TransferMG(lats[i - 1], lats[i], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
+    level_solve_objs[i - 1] = new StatefulMultigridMG::LevelSolveMG;
+    level_solve_objs[i - 1]->fine_stencil_app = QMG_MATVEC_ORIGINAL;
+    level_solve_objs[i - 1]->intermediate_tol = inner_tol;
+    level_solve_objs[i - 1]->intermediate_iters = inner_max_iter;
+    level_solve_objs[i - 1]->intermediate_restart_freq = inner_restart_freq;
+    level_solve_objs[i - 1]->pre_tol = pre_smooth_tol;
+    level_solve_objs[i - 1]->pre_iters = n_pre_smooth;
+    level_solve_objs[i - 1]->post_tol = post_smooth_tol;
+    level_solve_objs[i - 1]->post_iters = n_post_smooth;
+    mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, true, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL, null_vectors);
+    for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
+    delete[] null_vectors;
+    cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
+  }
+  qmg_stream_sync(0);
+  setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
+
+  return 0;
+}
+
+#endif

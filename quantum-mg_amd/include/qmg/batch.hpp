@@ -1,0 +1,399 @@
+// batch.hpp -- the K-cycle for a LOCK-STEP BATCH of independent right-hand sides (BASELINE configs[3]/[4]:
+// "independent right-hand sides", several per GPU).
+//
+// The reference solves one system at a time (tests/n13_wilson_kcycle/wilson_kcycle.cpp:459-466), so k systems stream
+// every coarse operator and every null vector k times.  Here up to 16 systems advance through the SAME iteration of the
+// SAME solver together: one launch per step for the whole batch, the matrices / null vectors read once, and the coarse
+// applies run as (nc x nc).(nc x k) contractions on the f64 matrix cores (qmg_stencil.hip kernel C).
+//
+// Semantics: each system sees exactly the iteration it would see alone.  Every scalar (alpha, residual norm, Gram-
+// Schmidt coefficient, restart decision, inner tolerance) is per system; a system that converges inside a solve is
+// FROZEN (its bit leaves the active mask: no kernel reads or writes it) while the rest continue.  The per-system
+// arithmetic is that of krylov.hpp / multigrid.hpp line by line -- element-wise kernels and reductions are
+// bit-identical to the single-vector ones, the MFMA apply and the blocked transfer differ in summation order only
+// (1e-13), so a batched solve reproduces the single solves to solver tolerance with the same iteration counts (+-1).
+//
+// Scope (this round): the ORIGINAL operator on every level with MR smoothers and GCR coarse solves, i.e. the n13
+// configuration (stateful_multigrid.h:734-1060 with fine_stencil_app = coarsest_stencil_app = QMG_MATVEC_ORIGINAL, no
+// CGNE/CGNR smoothers).  Other configurations are rejected loudly, not emulated.
+#ifndef QMG_BATCH_HPP
+#define QMG_BATCH_HPP
+
+#include <cmath>
+#include <iostream>
+#include <vector>
+
+#include "krylov.hpp"
+#include "multigrid.hpp"
+
+namespace qmg {
+
+const int BATCH_MAX = 16;
+
+// nrhs vectors, `stride` complex elements apart
+struct Batch {
+  complex<double>* p;
+  size_t stride;
+  int nrhs;
+  Batch() : p(0), stride(0), nrhs(0) {}
+  Batch(complex<double>* p_, size_t stride_, int nrhs_) : p(p_), stride(stride_), nrhs(nrhs_) {}
+  complex<double>* vec(int k) const { return p + (size_t)k * stride; }
+};
+
+inline unsigned full_mask(int nrhs) { return (nrhs >= 32) ? 0xFFFFFFFFu : ((1u << nrhs) - 1u); }
+inline bool is_active(unsigned mask, int k) { return (mask >> k) & 1u; }
+
+// batch scratch, recycled like VecPool
+struct BatchPool {
+  VecPool pool;
+  size_t stride;
+  int nrhs;
+  BatchPool(size_t n, int nrhs_) : pool(n * (size_t)nrhs_), stride(n), nrhs(nrhs_) {}
+  Batch get() { return Batch(pool.get(), stride, nrhs); }
+};
+
+typedef std::vector<complex<double>> cvec;
+
+inline void bblas(int op, const cvec* a, const cvec* b, const Batch* x, const Batch* y, Batch z, size_t n, unsigned mask) {
+  std::vector<double> fa, fb;
+  if (a) { fa.resize(2 * z.nrhs); for (int k = 0; k < z.nrhs; k++) { fa[2 * k] = (*a)[k].real(); fa[2 * k + 1] = (*a)[k].imag(); } }
+  if (b) { fb.resize(2 * z.nrhs); for (int k = 0; k < z.nrhs; k++) { fb[2 * k] = (*b)[k].real(); fb[2 * k + 1] = (*b)[k].imag(); } }
+  ok(qmg_batch_blas(op, a ? fa.data() : 0, b ? fb.data() : 0, x ? x->p : 0, y ? y->p : 0, z.p, n, z.nrhs, z.stride, mask, current_stream()), "qmg_batch_blas");
+}
+inline void bzero(Batch z, size_t n, unsigned mask) { bblas(QMG_BOP_ZERO, 0, 0, 0, 0, z, n, mask); }
+inline void bcopy(Batch z, Batch x, size_t n, unsigned mask) { bblas(QMG_BOP_COPY, 0, 0, &x, 0, z, n, mask); }
+inline void bcaxpy(const cvec& a, Batch x, Batch y, size_t n, unsigned mask) { bblas(QMG_BOP_CAXPY, &a, 0, &x, 0, y, n, mask); }   // y += a x
+inline void bcxpy(Batch x, Batch y, size_t n, unsigned mask) { bblas(QMG_BOP_CXPY, 0, 0, &x, 0, y, n, mask); }                   // y += x
+inline void bcaxpbyz(const cvec& a, Batch x, const cvec& b, Batch y, Batch z, size_t n, unsigned mask) { bblas(QMG_BOP_CAXPBYZ, &a, &b, &x, &y, z, n, mask); }
+inline void bxmyz(Batch x, Batch y, Batch z, size_t n, unsigned mask) {   // z = x - y
+  const cvec one(z.nrhs, 1.0), mone(z.nrhs, -1.0);
+  bcaxpbyz(one, x, mone, y, z, n, mask);
+}
+inline void bcxpyz(Batch x, Batch y, Batch z, size_t n, unsigned mask) {   // z = x + y
+  const cvec one(z.nrhs, 1.0);
+  bcaxpbyz(one, x, one, y, z, n, mask);
+}
+
+// per-system |x_k|^2; entries of frozen systems keep `fill`
+inline std::vector<double> bnorm2sq(Batch x, size_t n, unsigned mask, double fill = 0.0) {
+  std::vector<double> raw(2 * x.nrhs, 0.0), out(x.nrhs, fill);
+  ok(qmg_batch_reduce(QMG_BRED_NORM2, x.p, 0, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
+  for (int k = 0; k < x.nrhs; k++) if (is_active(mask, k)) out[k] = raw[2 * k];
+  return out;
+}
+inline std::vector<double> bdiffnorm2sq(Batch x, Batch y, size_t n, unsigned mask) {
+  std::vector<double> raw(2 * x.nrhs, 0.0), out(x.nrhs, 0.0);
+  ok(qmg_batch_reduce(QMG_BRED_DIFFNORM2, x.p, y.p, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
+  for (int k = 0; k < x.nrhs; k++) if (is_active(mask, k)) out[k] = raw[2 * k];
+  return out;
+}
+// d[k][j] = <xs[j]_k, y_k>
+inline std::vector<cvec> bmultidot(const std::vector<Batch>& xs, int nj, Batch y, size_t n, unsigned mask) {
+  std::vector<cvec> out(y.nrhs, cvec(nj, 0.0));
+  int done = 0;
+  while (done < nj) {   // the ABI takes up to 32 vector sets per call
+    const int jj = (nj - done > 32) ? 32 : nj - done;
+    std::vector<const void*> ptrs(jj);
+    for (int j = 0; j < jj; j++) ptrs[j] = xs[done + j].p;
+    std::vector<double> raw((size_t)2 * y.nrhs * jj, 0.0);
+    ok(qmg_batch_multidot(ptrs.data(), jj, y.p, n, y.nrhs, y.stride, mask, raw.data(), current_stream()), "qmg_batch_multidot");
+    for (int k = 0; k < y.nrhs; k++)
+      if (is_active(mask, k))
+        for (int j = 0; j < jj; j++) out[k][done + j] = complex<double>(raw[((size_t)k * jj + j) * 2], raw[((size_t)k * jj + j) * 2 + 1]);
+    done += jj;
+  }
+  return out;
+}
+// y_k += sum_j c[k][j] xs[j]_k
+inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<Batch>& xs, int nj, Batch y, size_t n, unsigned mask) {
+  if (nj <= 0) return;
+  std::vector<double> cf((size_t)2 * nj * y.nrhs, 0.0);
+  std::vector<const void*> ptrs(nj);
+  for (int j = 0; j < nj; j++) {
+    ptrs[j] = xs[j].p;
+    for (int k = 0; k < y.nrhs; k++) { cf[((size_t)j * y.nrhs + k) * 2] = c[k][j].real(); cf[((size_t)j * y.nrhs + k) * 2 + 1] = c[k][j].imag(); }
+  }
+  ok(qmg_batch_multi_caxpy(cf.data(), ptrs.data(), nj, y.p, n, y.nrhs, y.stride, mask, current_stream()), "qmg_batch_multi_caxpy");
+}
+
+}  // namespace qmg
+
+// lhs_k = A rhs_k for the active systems
+typedef void (*batch_matrix_op)(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data);
+typedef void (*batch_precond_op)(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb);
+
+inline void apply_stencil_2D_M_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data) {
+  ((Stencil2D*)extra_data)->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MR(omega) for a batch: minv_vector_minres of krylov.hpp per system, in lock step.  x0 = 0 is REQUIRED (every use in the
+// K-cycle; the caller has zeroed phi): r0 = b.
+// ---------------------------------------------------------------------------------------------
+inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi, qmg::Batch phi0, int size, int max_iter, double eps, double omega,
+                                                                   batch_matrix_op matrix_vector, void* extra_info, unsigned mask) {
+  const int nrhs = phi.nrhs;
+  std::vector<inversion_info> inv(nrhs);
+  qmg::BatchPool pool(phi.stride, nrhs);
+  qmg::Batch r = pool.get(), p = pool.get();
+  const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
+  qmg::bcopy(r, phi0, size, mask);
+  std::vector<double> rsq = bsq, rsq_ref = bsq, bnorm(nrhs);
+  std::vector<int> its(nrhs, 0), ops(nrhs, 0);
+  std::vector<bool> conv(nrhs, false);
+  unsigned act = 0;
+  for (int k = 0; k < nrhs; k++) {
+    bnorm[k] = std::sqrt(bsq[k]);
+    if (!qmg::is_active(mask, k)) continue;
+    conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < eps * bnorm[k]);
+    if (!conv[k] && max_iter > 0) act |= 1u << k;
+  }
+  std::vector<qmg::Batch> rp(2);
+  rp[0] = r; rp[1] = p;
+  while (act) {
+    matrix_vector(p, r, act, extra_info);
+    const std::vector<qmg::cvec> d2 = qmg::bmultidot(rp, 2, p, size, act);
+    qmg::cvec alpha(nrhs, 0.0), malpha(nrhs, 0.0);
+    unsigned upd = 0, renorm = 0;
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(act, k)) continue;
+      ops[k]++;
+      const complex<double> pr = std::conj(d2[k][0]);
+      const double pp = d2[k][1].real();
+      if (pp == 0.0) { act &= ~(1u << k); continue; }   // breakdown: this system stops (krylov.hpp `break`)
+      alpha[k] = omega * pr / pp; malpha[k] = -alpha[k];
+      upd |= 1u << k;
+      rsq[k] = rsq[k] - (2.0 * omega - omega * omega) * std::norm(pr) / pp;
+      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * eps * bnorm[k]) renorm |= 1u << k;
+    }
+    qmg::bcaxpy(alpha, r, phi, size, upd);
+    qmg::bcaxpy(malpha, p, r, size, upd);
+    if (renorm) {
+      const std::vector<double> t = qmg::bnorm2sq(r, size, renorm);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(renorm, k)) { rsq[k] = t[k]; rsq_ref[k] = t[k]; }
+    }
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(upd, k)) continue;
+      its[k]++;
+      if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+      else if (its[k] >= max_iter) act &= ~(1u << k);
+    }
+  }
+  for (int k = 0; k < nrhs; k++) { inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = "MinRes (batch)"; }
+  return inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flexible GCR with restarts for a batch: qmg_gcr_core of krylov.hpp per system, in lock step.  All systems start
+// together, so the basis index kb (and with it the restart points) is common; everything else is per system.
+// zero_guess: the caller has zeroed phi, r0 = b (krylov.hpp ZeroGuess).
+// ---------------------------------------------------------------------------------------------
+inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, int size, int max_iter, double eps, int restart_freq,
+                                             batch_matrix_op matrix_vector, void* extra_info, batch_precond_op precond, void* precond_info,
+                                             unsigned mask, bool zero_guess, inversion_verbose_struct* verb, const char* name) {
+  const int nrhs = phi.nrhs;
+  std::vector<inversion_info> inv(nrhs);
+  const int basis_max = (restart_freq > 0) ? restart_freq : max_iter;
+  qmg::BatchPool pool(phi.stride, nrhs);
+  qmg::Batch r = pool.get(), tmp = pool.get();
+  std::vector<qmg::Batch> Z, W;
+  std::vector<std::vector<double>> Wnorm2;   // [basis index][system]
+  const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
+  std::vector<double> rsq(nrhs, 0.0), rsq_ref(nrhs, 0.0), bnorm(nrhs, 0.0);
+  std::vector<int> its(nrhs, 0), ops(nrhs, 0);
+  std::vector<bool> conv(nrhs, false);
+  if (zero_guess) { qmg::bcopy(r, phi0, size, mask); rsq = bsq; }
+  else {
+    matrix_vector(tmp, phi, mask, extra_info);
+    for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) ops[k]++;
+    qmg::bxmyz(phi0, tmp, r, size, mask);
+    rsq = qmg::bnorm2sq(r, size, mask);
+  }
+  unsigned act = 0;
+  for (int k = 0; k < nrhs; k++) {
+    bnorm[k] = std::sqrt(bsq[k]);
+    rsq_ref[k] = rsq[k];
+    if (!qmg::is_active(mask, k)) continue;
+    conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < eps * bnorm[k]);
+    if (!conv[k] && max_iter > 0) act |= 1u << k;
+  }
+  int kb = 0;
+  inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
+  if (verb) { pverb.precond_verbosity = verb->precond_verbosity; pverb.precond_verb_prefix = verb->precond_verb_prefix; }
+  std::vector<qmg::Batch> rw(2);
+  while (act) {
+    if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(std::vector<double>(nrhs, 0.0)); }
+    qmg::Batch z = Z[kb], w = W[kb];
+    if (precond) { qmg::bzero(z, size, act); precond(z, r, size, act, precond_info, &pverb); }
+    else qmg::bcopy(z, r, size, act);
+    matrix_vector(w, z, act, extra_info);
+    if (kb > 0) {
+      std::vector<qmg::cvec> c = qmg::bmultidot(W, kb, w, size, act);
+      for (int k = 0; k < nrhs; k++)
+        if (qmg::is_active(act, k))
+          for (int i = 0; i < kb; i++) c[k][i] = -c[k][i] / Wnorm2[i][k];
+      qmg::bmulti_caxpy(c, W, kb, w, size, act);
+      qmg::bmulti_caxpy(c, Z, kb, z, size, act);
+    }
+    rw[0] = r; rw[1] = w;
+    const std::vector<qmg::cvec> d2 = qmg::bmultidot(rw, 2, w, size, act);
+    qmg::cvec alpha(nrhs, 0.0), malpha(nrhs, 0.0);
+    unsigned upd = 0, renorm = 0;
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(act, k)) continue;
+      ops[k]++;
+      const double ww = d2[k][1].real();
+      if (ww == 0.0) { act &= ~(1u << k); continue; }
+      Wnorm2[kb][k] = ww;
+      const complex<double> wr = std::conj(d2[k][0]);
+      alpha[k] = wr / ww; malpha[k] = -alpha[k];
+      upd |= 1u << k;
+      rsq[k] = rsq[k] - std::norm(wr) / ww;
+      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * eps * bnorm[k]) renorm |= 1u << k;
+    }
+    qmg::bcaxpy(alpha, z, phi, size, upd);
+    qmg::bcaxpy(malpha, w, r, size, upd);
+    if (renorm) {
+      const std::vector<double> t = qmg::bnorm2sq(r, size, renorm);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(renorm, k)) { rsq[k] = t[k]; rsq_ref[k] = t[k]; }
+    }
+    kb++;
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(upd, k)) continue;
+      its[k]++;
+      if (verb && verb->verbosity == VERB_DETAIL) std::cout << verb->verb_prefix << name << " rhs " << k << " Iter " << its[k] << " RelTol " << std::sqrt(rsq[k]) / bnorm[k] << "\n";
+      if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+    }
+    if (act && kb == basis_max) {   // restart: true residual, drop the basis (before the iteration cap, as in krylov.hpp)
+      matrix_vector(tmp, phi, act, extra_info);
+      qmg::bxmyz(phi0, tmp, r, size, act);
+      const std::vector<double> t = qmg::bnorm2sq(r, size, act);
+      kb = 0;
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        ops[k]++;
+        rsq[k] = t[k]; rsq_ref[k] = t[k];
+        if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+      }
+    }
+    for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k) && its[k] >= max_iter) act &= ~(1u << k);
+  }
+  for (int k = 0; k < nrhs; k++) {
+    inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = name;
+    if (verb && verb->verbosity != VERB_NONE && qmg::is_active(mask, k))
+      std::cout << verb->verb_prefix << name << " rhs " << k << (conv[k] ? " Success " : " Fail ") << "Iter " << its[k] << " RelTol " << (bnorm[k] > 0 ? std::sqrt(rsq[k]) / bnorm[k] : 0.0) << "\n";
+  }
+  return inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One K-cycle application for the active systems of a batch: StatefulMultigridMG::mg_preconditioner
+// (multigrid.hpp; stateful_multigrid.h:734-1060) step for step.  extra_data is a BatchKcycle.
+// ---------------------------------------------------------------------------------------------
+struct BatchKcycle {
+  StatefulMultigridMG* mg;
+  int nrhs;
+  BatchKcycle(StatefulMultigridMG* mg_, int nrhs_) : mg(mg_), nrhs(nrhs_) {}
+  // the configuration the batched cycle implements
+  bool supported() {
+    const int nl = mg->get_num_levels();
+    for (int i = 0; i < nl - 1; i++) {
+      StatefulMultigridMG::LevelSolveMG* ls = mg->get_level_solve(i);
+      if (!ls || ls->fine_stencil_app != QMG_MATVEC_ORIGINAL || ls->pre_cgne || ls->post_cgne) return false;
+    }
+    return mg->get_coarsest_solve()->coarsest_stencil_app == QMG_MATVEC_ORIGINAL && nl >= 2;
+  }
+};
+
+inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb) {
+  BatchKcycle* bk = (BatchKcycle*)extra_data;
+  StatefulMultigridMG* mg = bk->mg;
+  const int nrhs = bk->nrhs;
+  const int level = mg->get_multigrid_level();
+  const int total_num_levels = mg->get_num_levels();
+  Stencil2D* fine_stencil = mg->get_stencil(level);
+  Stencil2D* coarse_stencil = mg->get_stencil(level + 1);
+  TransferMG* transfer = mg->get_transfer(level);
+  StatefulMultigridMG::LevelSolveMG* level_solve = mg->get_level_solve();
+  const size_t fine_size = (size_t)mg->get_lattice(level)->get_size_cv_l();
+  const size_t coarse_size = (size_t)mg->get_lattice(level + 1)->get_size_cv_l();
+
+  inversion_verbose_struct verb2(VERB_SUMMARY, std::string(" "));
+  if (verb == 0 || verb->verbosity == VERB_NONE) { verb2.verbosity = VERB_NONE; verb2.precond_verbosity = VERB_NONE; }
+  else verb2.precond_verbosity = VERB_SUMMARY;
+  verb2.verb_prefix = "  ";
+  for (int i = 1; i < level + 1; i++) verb2.verb_prefix += "  ";
+  verb2.verb_prefix += "[QMG-MG-SOLVE-INFO]: Level " + std::to_string(level + 1) + " ";
+
+  int coarse_max_iter, coarse_restart;
+  double coarse_tol;
+  if (level < total_num_levels - 2) {
+    StatefulMultigridMG::LevelSolveMG* cs = mg->get_level_solve(level + 1);
+    coarse_max_iter = cs->intermediate_iters; coarse_tol = cs->intermediate_tol; coarse_restart = cs->intermediate_restart_freq;
+  } else {
+    StatefulMultigridMG::CoarsestSolveMG* cs = mg->get_coarsest_solve();
+    coarse_max_iter = cs->coarsest_iters; coarse_tol = cs->coarsest_tol; coarse_restart = cs->coarsest_restart_freq;
+  }
+
+  // scratch for this level (recycled through VecPool's per-length free lists)
+  qmg::BatchPool fpool(fine_size, nrhs), cpool(coarse_size, nrhs);
+  qmg::Batch Atmp = fpool.get(), z1 = fpool.get(), r1 = fpool.get();
+  auto count = [&](QMGDslashType type, const std::vector<inversion_info>& inv, int lvl) {
+    for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) mg->add_tracker_count(type, inv[k].ops_count, lvl);
+  };
+  int nact = 0;
+  for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) nact++;
+
+  // ---- 1. pre-smooth: A z1 ~ rhs, r1 = rhs - A z1
+  qmg::bzero(z1, fine_size, mask);
+  if (level_solve->pre_iters > 0) {
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z1, rhs, (int)fine_size, level_solve->pre_iters, level_solve->pre_tol, 0.85,
+                                                                      apply_stencil_2D_M_batch, (void*)fine_stencil, mask);
+    count(QMG_DSLASH_TYPE_PRESMOOTH, inv, level);
+    apply_stencil_2D_M_batch(Atmp, z1, mask, (void*)fine_stencil);
+    mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
+    qmg::bxmyz(rhs, Atmp, r1, fine_size, mask);
+  } else {
+    qmg::bcopy(r1, rhs, fine_size, mask);
+    qmg::bcopy(z1, rhs, fine_size, mask);
+  }
+
+  // ---- 2. restrict, coarse solve (recursion = the "K"), prolong
+  qmg::Batch r_coarse = cpool.get(), e_coarse = cpool.get();
+  qmg::bzero(r_coarse, coarse_size, mask);
+  transfer->restrict_f2c_batch(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
+  // (ORIGINAL operator: prepare_M is a copy, so rnorm_prep == rnorm and the inner tolerance is coarse_tol, multigrid.hpp)
+  qmg::bzero(e_coarse, coarse_size, mask);
+  std::vector<inversion_info> cinv;
+  if (level == total_num_levels - 2) {
+    cinv = bgcr_core(e_coarse, r_coarse, (int)coarse_size, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_2D_M_batch, (void*)coarse_stencil, 0, 0,
+                     mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart");
+  } else {
+    mg->go_coarser();
+    cinv = bgcr_core(e_coarse, r_coarse, (int)coarse_size, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_2D_M_batch, (void*)coarse_stencil,
+                     mg_preconditioner_batch, (void*)bk, mask, true, &verb2, coarse_restart == -1 ? "VPGCR" : "VPGCR-restart");
+    mg->go_finer();
+  }
+  for (int k = 0; k < nrhs; k++)
+    if (qmg::is_active(mask, k)) { mg->add_tracker_count(QMG_DSLASH_TYPE_KRYLOV, cinv[k].ops_count, level + 1); mg->add_iterations_count(cinv[k].iter, level + 1); }
+
+  // ---- 3. prolong and correct: lhs = z1 + P e
+  qmg::Batch z2 = r1;   // r1 is free again
+  qmg::bzero(z2, fine_size, mask);
+  transfer->prolong_c2f_batch(e_coarse.p, e_coarse.stride, z2.p, z2.stride, nrhs, mask);
+  qmg::bcxpyz(z1, z2, lhs, fine_size, mask);
+
+  // ---- 4. post-smooth on r2 = rhs - A lhs
+  if (level_solve->post_iters > 0) {
+    apply_stencil_2D_M_batch(Atmp, lhs, mask, (void*)fine_stencil);
+    qmg::Batch r2 = z2, z3 = z1;   // both free again
+    qmg::bxmyz(rhs, Atmp, r2, fine_size, mask);
+    qmg::bzero(z3, fine_size, mask);
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z3, r2, (int)fine_size, level_solve->post_iters, level_solve->post_tol, 0.85,
+                                                                      apply_stencil_2D_M_batch, (void*)fine_stencil, mask);
+    count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
+    qmg::bcxpy(z3, lhs, fine_size, mask);
+  }
+}
+
+#endif

@@ -10,5 +10,6 @@
 #include "coarse.hpp"
 #include "krylov.hpp"
 #include "multigrid.hpp"
+#include "batch.hpp"
 #include "u1.hpp"
 #endif

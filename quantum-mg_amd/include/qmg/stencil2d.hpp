@@ -243,6 +243,12 @@ struct Stencil2D {
   }
   // lhs = A rhs without a separate zeroing pass (what the C wrappers do, :2571-2576)
   void apply_M_overwrite(complex<double>* lhs, complex<double>* rhs) { launch(QMG_P_ALL | QMG_P_ZERO, lhs, rhs); }
+  // lhs_k = M rhs_k for the active systems of a lock-step batch (<= 16 vectors `stride` apart): one read of the matrices;
+  // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
+  void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {
+    qmg_stencil_desc d = desc();
+    qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, QMG_P_ALL | QMG_P_ZERO, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
+  }
 
   complex<double> get_shift() { return shift; }
   complex<double> get_shift_eo() { return eo_shift; }

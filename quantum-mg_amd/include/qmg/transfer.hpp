@@ -128,6 +128,19 @@ class TransferMG {
                          qmg::current_stream()), "qmg_restrict");
   }
 
+  // The same two maps for a lock-step batch of right-hand sides (qmg_batch.hip): the null vectors are streamed once per
+  // 8 active systems instead of once per system.  Frozen systems (mask bit clear) are not touched.
+  void prolong_c2f_batch(complex<double>* coarse, size_t cstride, complex<double>* fine, size_t fstride, int nrhs, unsigned mask) {
+    qmg::ok(qmg_prolong_batch(null_store, const_num_null_vec, coarse, fine, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
+                              coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), nrhs, cstride, fstride, mask,
+                              qmg::current_stream()), "qmg_prolong_batch");
+  }
+  void restrict_f2c_batch(complex<double>* fine, size_t fstride, complex<double>* coarse, size_t cstride, int nrhs, unsigned mask) {
+    qmg::ok(qmg_restrict_batch(restrict_store ? restrict_store : null_store, const_num_null_vec, fine, coarse, fine_lat->get_dim_mu(0),
+                               fine_lat->get_dim_mu(1), fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(),
+                               nrhs, fstride, cstride, mask, qmg::current_stream()), "qmg_restrict_batch");
+  }
+
   bool is_symmetric() { return restrict_store == 0; }
   bool has_decompositions() { return is_symmetric() ? (block_cholesky != 0) : (block_L != 0 && block_U != 0); }
   void copy_cholesky(complex<double>* save_cholesky) {
