@@ -223,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong(const cplx* __restrict__ nul
 }
 
 // coarse_k[ci*cnc + d] += sum_{e in block ci} conj(null[d][e]) fine_k[e]     (transfer.h:487-511)
-// A group of TG threads (a power of two, 2..256, >= the block's element count when that is <= 256) owns one coarse site;
+// A group of TG threads (a power of two, 2..256, about an eighth of the block's element count) owns one coarse site;
 // a workgroup carries 256/TG consecutive coarse sites of a coarse row, so neighbouring groups read neighbouring fine
 // runs.  Thread l of a group walks elements l, l+TG, ...; DC null vectors x KB systems of partial sums per thread; the
 // group sum is a fixed-order shuffle butterfly (inside a wavefront) plus an LDS pass (across the wavefronts of a wide
@@ -478,8 +478,11 @@ int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* c
   if (bi.n == 0) return QMG_SUCCESS;
   const long ncs = (long)cLx * cLy;
   const int nel = g.bx * g.by * g.fnc;
+  // threads per coarse site: ~8 block elements per thread, so that the cross-lane butterfly (2 DC KB log2(TG) shuffles per
+  // pass) stays small next to the 8 DC KB complex MACs a thread does per pass (one element per thread made the L0->L1
+  // restriction shuffle-bound: 6.3 ms for 8 systems against 0.57 ms per system in the single-vector kernel)
   int TG = 2;
-  while (TG < nel && TG < BLOCK) TG <<= 1;
+  while (TG * 2 <= nel / 8 && TG < BLOCK) TG <<= 1;
   const long ngroups = (ncs + BLOCK / TG - 1) / (BLOCK / TG);
   unsigned gx = (unsigned)(ngroups > 262144 ? 262144 : ngroups);
   for (int s0 = 0; s0 < bi.n; s0 += 8) {

@@ -111,3 +111,29 @@ def test_wilson_kcycle_matches_oracle(golden_dir, L, n_refine, coarse_dof, mass)
     # pre = n_pre + 1 (residual), post = n_post per outer iteration -- one fewer each than the reference's accounting.
     m = re.search(r"Level 0 NullVec 0 PreSmooth (\d+) Krylov 0 PostSmooth (\d+)", out.stdout)
     assert int(m.group(1)) == 3 * gpu_iters and int(m.group(2)) == 2 * gpu_iters
+
+
+@pytest.mark.parametrize("L,n_refine,coarse_dof,nrhs,point", [(64, 2, 8, 5, False), (64, 2, 8, 3, True), (64, 1, 12, 16, False), (64, 1, 24, 2, True)])
+def test_batched_kcycle_reproduces_the_single_solves(golden_dir, L, n_refine, coarse_dof, nrhs, point):
+    """include/qmg/batch.hpp: up to 16 systems advance through one K-cycle iteration together (coarse applies on the
+    f64 matrix cores, null vectors streamed once per step).  `verify` re-solves every system alone through the
+    single-vector path: iteration counts equal (+-1), solutions equal to solver accuracy, every true residual <= 1e-10.
+    With `point`, system 1 is a point source and converges on its own schedule, so the outer-level freeze masks are
+    exercised as well as the inner ones (coarse solves converge per system all the time).  (L = 64 only: on the 128^2
+    fixture at this mass the 8x8 coarsest GCR stagnates for 1000 iterations per call in BOTH paths -- slow, not wrong.)"""
+    gauge_file = os.path.join(golden_dir, "l%dt%db60_heatbath.dat" % (L, L))
+    env = dict(os.environ, QMG_QUIET="1")
+    if point:
+        env["QMG_MRHS_POINT"] = "1"
+    out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle_mrhs"), str(L), "-0.07", "6.0", str(n_refine), str(coarse_dof), gauge_file, str(L), str(nrhs), "verify"],
+                         cwd=DRIVERS, env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+    rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+    assert len(rows) == nrhs
+    assert all(float(r[3]) <= 1.05e-10 for r in rows)
+    ver = re.findall(r"\[QMG-MRHS-VERIFY\]: rhs (\d+) single-path iterations (\d+) \(batched (\d+)\) ; relative solution difference ([-\d.e+]+)", out.stdout)
+    assert len(ver) == nrhs
+    for _, single_it, batch_it, diff in ver:
+        assert abs(int(single_it) - int(batch_it)) <= 1
+        assert float(diff) < 1e-7
