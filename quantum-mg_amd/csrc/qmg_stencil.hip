@@ -24,6 +24,7 @@
 // Kernel B (any nc, used for the Galerkin coarse operators): see below.
 
 #include <string.h>
+#include <type_traits>
 
 #include "qmg_common.h"
 
@@ -495,7 +496,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 #pragma unroll
       for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    cplx G[NG], B[2][KS];
+    cplx G[NG];
+    // MODE 1 needs only the half of X its column carries (re for columns 0-7, im for 8-15): one double per k-step
+    typename std::conditional<MODE == 1, double, cplx>::type B[2][KS];
     auto load_piece = [&](int pc, int set) {      // global -> registers: matrix (lane-linear) and the k right-hand sides
       const cplx* m = ((pc == 0) ? a.clover : a.hopping + (long)(pc - 1) * a.size_cm) + site * NC2;
 #pragma unroll
@@ -507,7 +510,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 #pragma unroll
       for (int q = 0; q < KS; q++) {
         const int c = 4 * q + lq;
-        B[set][q] = (kval && c < NC) ? x[c] : cmake(0.0, 0.0);
+        const cplx xv = (kval && c < NC) ? x[c] : cmake(0.0, 0.0);
+        if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
+        else B[set][q] = xv;
       }
     };
     auto park_piece = [&]() {                     // registers -> this wavefront's LDS slice, padded rows
@@ -528,12 +533,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           const int r = 16 * t + lr, c = 4 * q + lq;
           Af[t] = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds[r * RS + c] : cmake(0.0, 0.0);
         }
-        if (a.ablate & 8) {   // diagnostic: operands kept alive by one vector FMA each, no matrix-core work
-#pragma unroll
-          for (int t = 0; t < RT; t++) { acc[0][t][0] = fma(Af[t].x, B[set][q].x, acc[0][t][0]); acc[1][t][0] = fma(Af[t].y, B[set][q].y, acc[1][t][0]); }
-          continue;
-        }
-        if (MODE == 0) {
+        if constexpr (MODE == 0) {
 #pragma unroll
           for (int t = 0; t < RT; t++) {
             acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q].x, acc[0][t], 0, 0, 0);
@@ -545,11 +545,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
             acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q].x, acc[1][t], 0, 0, 0);
           }
         } else {
-          const double bp = (lr < 8) ? B[set][q].x : B[set][q].y;
 #pragma unroll
           for (int t = 0; t < RT; t++) {
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, bp, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, bp, acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q], acc[1][t], 0, 0, 0);
           }
         }
       }
