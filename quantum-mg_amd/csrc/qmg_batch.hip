@@ -62,7 +62,12 @@ __global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(cplx* __restrict__ y, co
   const long off = (long)k * stride;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     cplx acc = y[off + i];
-    for (int j = 0; j < nj; j++) cmac(acc, m.a[j][k], m.x[j][off + i]);
+    for (int j = 0; j < nj; j++) {
+      const cplx c = m.a[j][k];
+      // a zero coefficient means "this system does not use vector set j" (systems of a batch own different numbers of
+      // directions): the slot may hold stale pool memory, which must not be read (0 * inf = nan)
+      if (c.x != 0.0 || c.y != 0.0) cmac(acc, c, m.x[j][off + i]);
+    }
     y[off + i] = acc;
   }
 }

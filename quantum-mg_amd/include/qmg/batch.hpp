@@ -196,8 +196,25 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
   const int basis_max = (restart_freq > 0) ? restart_freq : max_iter;
   qmg::BatchPool pool(phi.stride, nrhs);
   qmg::Batch r = pool.get(), tmp = pool.get();
-  std::vector<qmg::Batch> Z, W;
+  std::vector<qmg::Batch> Z, W;             // raw search directions and orthogonalised images (krylov.hpp: z is not orthogonalised)
   std::vector<std::vector<double>> Wnorm2;   // [basis index][system]
+  std::vector<std::vector<qmg::cvec>> C(nrhs);   // C[system][k][i]: Gram-Schmidt coefficients of this cycle
+  std::vector<qmg::cvec> alphas(nrhs);           // alphas[system][k]
+  std::vector<int> used(nrhs, 0);                // directions system k has taken in this cycle
+  auto flush_x = [&]() {                         // x_k += sum_j y_kj z_j for every system with pending directions
+    int K = 0;
+    unsigned m = 0;
+    for (int k = 0; k < nrhs; k++) if (used[k] > 0) { m |= 1u << k; if (used[k] > K) K = used[k]; }
+    if (!m) return;
+    std::vector<qmg::cvec> y(nrhs, qmg::cvec(K, 0.0));
+    for (int k = 0; k < nrhs; k++) {
+      if (used[k] <= 0) continue;
+      const qmg::cvec yk = qmg::gcr_direction_weights(alphas[k], C[k], used[k]);
+      for (int j = 0; j < used[k]; j++) y[k][j] = yk[j];
+      used[k] = 0;
+    }
+    qmg::bmulti_caxpy(y, Z, K, phi, size, m);
+  };
   const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
   std::vector<double> rsq(nrhs, 0.0), rsq_ref(nrhs, 0.0), bnorm(nrhs, 0.0);
   std::vector<int> its(nrhs, 0), ops(nrhs, 0);
@@ -223,6 +240,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
   std::vector<qmg::Batch> rw(2);
   while (act) {
     if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(std::vector<double>(nrhs, 0.0)); }
+    for (int k = 0; k < nrhs; k++) { if ((int)C[k].size() <= kb) { C[k].push_back(qmg::cvec()); alphas[k].push_back(0.0); } }
     qmg::Batch z = Z[kb], w = W[kb];
     if (precond) { qmg::bzero(z, size, act); precond(z, r, size, act, precond_info, &pverb); }
     else qmg::bcopy(z, r, size, act);
@@ -233,7 +251,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
         if (qmg::is_active(act, k))
           for (int i = 0; i < kb; i++) c[k][i] = -c[k][i] / Wnorm2[i][k];
       qmg::bmulti_caxpy(c, W, kb, w, size, act);
-      qmg::bmulti_caxpy(c, Z, kb, z, size, act);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k)) C[k][kb] = c[k];
     }
     rw[0] = r; rw[1] = w;
     const std::vector<qmg::cvec> d2 = qmg::bmultidot(rw, 2, w, size, act);
@@ -247,11 +265,12 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
       Wnorm2[kb][k] = ww;
       const complex<double> wr = std::conj(d2[k][0]);
       alpha[k] = wr / ww; malpha[k] = -alpha[k];
+      alphas[k][kb] = alpha[k];
+      used[k] = kb + 1;
       upd |= 1u << k;
       rsq[k] = rsq[k] - std::norm(wr) / ww;
       if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * eps * bnorm[k]) renorm |= 1u << k;
     }
-    qmg::bcaxpy(alpha, z, phi, size, upd);
     qmg::bcaxpy(malpha, w, r, size, upd);
     if (renorm) {
       const std::vector<double> t = qmg::bnorm2sq(r, size, renorm);
@@ -264,6 +283,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
       if (verb && verb->verbosity == VERB_DETAIL) std::cout << verb->verb_prefix << name << " rhs " << k << " Iter " << its[k] << " RelTol " << std::sqrt(rsq[k]) / bnorm[k] << "\n";
       if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
     }
+    if (kb == basis_max) flush_x();   // the basis is about to be reused: bring every pending x up to date (frozen systems too)
     if (act && kb == basis_max) {   // restart: true residual, drop the basis (before the iteration cap, as in krylov.hpp)
       matrix_vector(tmp, phi, act, extra_info);
       qmg::bxmyz(phi0, tmp, r, size, act);
@@ -278,6 +298,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
     }
     for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k) && its[k] >= max_iter) act &= ~(1u << k);
   }
+  flush_x();
   for (int k = 0; k < nrhs; k++) {
     inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = name;
     if (verb && verb->verbosity != VERB_NONE && qmg::is_active(mask, k))

@@ -76,6 +76,14 @@ inline void multi_caxpy(const std::vector<complex<double>>& a, const std::vector
   ok(qmg_multi_caxpy(cf.data(), ptrs.data(), k, y, n, current_stream()), "qmg_multi_caxpy");
 }
 
+// GCR with raw search directions: y_j such that sum_k alpha_k z'_k = sum_j y_j z_j, z'_k = z_k + sum_{i<k} c[k][i] z'_i
+inline std::vector<complex<double>> gcr_direction_weights(const std::vector<complex<double>>& alpha, const std::vector<std::vector<complex<double>>>& c, int K) {
+  std::vector<complex<double>> beta(alpha.begin(), alpha.begin() + K);
+  for (int k = K - 1; k >= 0; k--)
+    for (int i = 0; i < k; i++) beta[i] += beta[k] * c[k][i];
+  return beta;
+}
+
 }  // namespace qmg
 
 // ---------------------------------------------------------------------------------------------
@@ -199,6 +207,12 @@ inline inversion_info minv_vector_cg_restart(complex<double>* phi, complex<doubl
 //          w_k = A z_k ; orthogonalise w_k against w_0..w_{k-1} (and carry z_k along)
 //          alpha = <w_k, r>/<w_k,w_k> ; x += alpha z_k ; r -= alpha w_k
 //   restart_freq > 0: the basis is dropped every restart_freq directions.
+// The z_k are NOT orthogonalised explicitly.  With c_ik the Gram-Schmidt coefficients of w_k, the conjugate
+// directions are z'_k = z_k + sum_{i<k} c_ik z'_i and x = x0 + sum_k alpha_k z'_k = x0 + sum_j y_j z_j, where y
+// follows from alpha and c by a k x k back-substitution on the host (qmg::gcr_direction_weights).  x is only needed
+// at a restart and at exit, so the k-vector pass "z_k -= sum c_ik Z_i" of every iteration (a third of GCR's BLAS-1
+// traffic) becomes ONE multi-axpy per restart cycle.  w_k, r and every scalar -- hence every convergence decision --
+// are computed exactly as before; x differs by rounding only.
 // ---------------------------------------------------------------------------------------------
 inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, int size, int max_iter, double eps, int restart_freq,
                                    matrix_op_cplx matrix_vector, void* extra_info, precond_op_cplx precond, void* precond_info,
@@ -209,8 +223,14 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
   qmg::VecPool pool(size);
   complex<double>* r = pool.get();
   complex<double>* tmp = pool.get();
-  std::vector<complex<double>*> Z, W;     // search directions and their images, allocated on demand
+  std::vector<complex<double>*> Z, W;     // raw search directions z_k and orthogonalised images w'_k, allocated on demand
   std::vector<double> Wnorm2;
+  std::vector<std::vector<complex<double>>> C;   // C[k][i] = Gram-Schmidt coefficient of w_k against w'_i (i < k), this cycle
+  std::vector<complex<double>> alphas;           // alpha_k of this cycle
+  auto flush_x = [&](int K) {                    // x += sum_k alpha_k z'_k for the K directions of this cycle
+    if (K <= 0) return;
+    qmg::multi_caxpy(qmg::gcr_direction_weights(alphas, C, K), Z, K, phi, size);
+  };
   const double bsq = norm2sq(phi0, size);
   const double bnorm = std::sqrt(bsq);
   int ops = 0;
@@ -227,17 +247,18 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
   inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
   if (verb) { pverb.precond_verbosity = verb->precond_verbosity; pverb.precond_verb_prefix = verb->precond_verb_prefix; }
   while (!conv && k < max_iter) {
-    if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(0.0); }
+    if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(0.0); C.push_back(std::vector<complex<double>>()); alphas.push_back(0.0); }
     complex<double>* z = Z[kb];
     complex<double>* w = W[kb];
     if (precond) { zero_vector(z, size); precond(z, r, size, precond_info, &pverb); }
     else copy_vector(z, r, size);
     matrix_vector(w, z, extra_info); ops++;
-    if (kb > 0) {   // Gram-Schmidt against the current basis: ONE multi-dot pass, then TWO fused multi-axpy passes
+    C[kb].clear();
+    if (kb > 0) {   // Gram-Schmidt of w against the current basis: ONE multi-dot pass, ONE fused multi-axpy pass
       std::vector<complex<double>> c = qmg::multidot(W, kb, w, size);
       for (int i = 0; i < kb; i++) c[i] = -c[i] / Wnorm2[i];
       qmg::multi_caxpy(c, W, kb, w, size);
-      qmg::multi_caxpy(c, Z, kb, z, size);
+      C[kb] = c;
     }
     // <r,w> and <w,w> in one pass over w
     std::vector<complex<double>*> rw = {r, w};
@@ -247,7 +268,7 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
     Wnorm2[kb] = ww;
     const complex<double> wr = std::conj(d2[0]);   // <w,r>
     const complex<double> alpha = wr / ww;
-    caxpy(alpha, z, phi, size);
+    alphas[kb] = alpha;
     caxpy(-alpha, w, r, size);
     // |r - alpha w|^2 = |r|^2 - |<w,r>|^2 / <w,w>: no extra reduction; confirmed by a true norm near convergence
     // (the subtraction loses absolute accuracy ~1e-16 * rsq_ref: re-anchor with a true norm after every 8 orders of magnitude)
@@ -256,7 +277,8 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
     k++; kb++;
     qmg::report(verb, name, k, std::sqrt(rsq) / bnorm);
     if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
-    if (kb == basis_max) {   // restart: recompute the true residual, drop the basis
+    if (kb == basis_max) {   // restart: bring x up to date, recompute the true residual, drop the basis
+      flush_x(kb);
       matrix_vector(tmp, phi, extra_info); ops++;
       caxpbyz(1.0, phi0, -1.0, tmp, r, size);
       rsq = norm2sq(r, size);
@@ -266,6 +288,7 @@ inline inversion_info qmg_gcr_core(complex<double>* phi, complex<double>* phi0, 
       if (std::sqrt(rsq) < eps * bnorm) { conv = true; break; }
     }
   }
+  flush_x(kb);   // (kb == 0 right after a restart: nothing pending)
   invif.success = conv; invif.iter = k; invif.resSq = rsq; invif.ops_count = ops;
   qmg::summary(verb, name, conv, k, bnorm > 0 ? std::sqrt(rsq) / bnorm : 0.0);
   return invif;
