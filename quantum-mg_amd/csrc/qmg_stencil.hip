@@ -351,6 +351,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
       while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
       auto prefetch = [&](int piece) {
         const cplx* msrc = (piece == 4) ? a.clover + site0 * nc2 : a.hopping + (long)piece * a.size_cm + site0 * nc2;
+        if ((a.ablate & 16) && (piece == 2 || piece == 3)) {
+          // diagnostic (wrong arithmetic, right access pattern): what the backward hops would cost if they re-read the
+          // neighbour's FORWARD link (gamma5-hermitian link compression) instead of streaming their own array
+          long nsite0 = (piece == 2) ? opp + (long)y * a.hr + (j0 + s - 1 < 0 ? 0 : j0 + s - 1) : opp + (long)ym * a.hr + j0;
+          if (nsite0 + nsite > 2 * a.half_vol) nsite0 = 2 * a.half_vol - nsite;
+          msrc = a.hopping + (long)(piece - 2) * a.size_cm + nsite0 * nc2;
+        }
         const int lim = nsite * (int)nc2;
 #pragma unroll
         for (int q = 0; q < PT; q++) {

@@ -67,7 +67,12 @@ static TransferMG* build_coarse_by_restrict(Setup& s, int fine_level, Lattice2D*
     copy_vector(null_vectors[j], s.test_vectors[fine_idx][j], n);
     mg->get_stencil(fine_idx)->chiral_projection_both(null_vectors[j], null_vectors[j + coarse_dof / 2]);
   }
-  TransferMG* transfer_obj = new TransferMG(mg->get_lattice(fine_idx), coarse_lat, null_vectors, true);
+  // n22:682 passes no doubling type here (QMG_DOUBLE_NONE), so the operator built from this transfer has no notion of
+  // chirality (coarse.h:104-116) and, one level further down, chiral_projection_both leaves every "down" partner zero:
+  // block-orthonormalising those divides by zero, and a hierarchy of four or more levels is all NaN -- in the reference
+  // as here (BASELINE configs[4] asks for four levels).  Declaring the doubling changes nothing for <= 3 levels (the
+  // flag of the coarsest operator is never read) and makes deeper hierarchies work.
+  TransferMG* transfer_obj = new TransferMG(mg->get_lattice(fine_idx), coarse_lat, null_vectors, true, false, QMG_DOUBLE_PROJECTION);
   if (s.schur && !mg->get_stencil(fine_idx)->built_rbjacobi) mg->get_stencil(fine_idx)->build_rbjacobi_stencil();
   if (fresh_build) mg->push_level(coarse_lat, transfer_obj, new_level_solve, true, true, coarsen_from(s), build_extra(s), null_vectors);
   else mg->update_level(coarse_idx, coarse_lat, transfer_obj, new_level_solve, true, true, coarsen_from(s), build_extra(s), null_vectors);
@@ -185,20 +190,48 @@ int main(int argc, char** argv) {
       const int fine_idx = i, coarse_idx = i + 1;
       const long n = lats[fine_idx]->get_size_cv_l();
       complex<double>** null_vectors = new complex<double>*[coarse_dof];
+      // The coarse_dof/2 relaxations of one level are independent systems (each reads only its own test vector and the
+      // CURRENT hierarchy; the Gram-Schmidt below touches vector j alone), so in the ORIGINAL-operator configuration
+      // they advance in lock step through the batched K-cycle (include/qmg/batch.hpp) -- same results, the coarse
+      // operators and null vectors streamed once per step for all of them (SURVEY 8e "setup phase").
+      const int nb = coarse_dof / 2;
+      const bool batched_setup = !schur && nb <= qmg::BATCH_MAX && getenv("QMG_NO_BATCHED_SETUP") == 0;
+      if (batched_setup) {
+        BatchKcycle bk(mg_object, nb);
+        qmg::BatchPool bpool((size_t)n, nb);
+        qmg::Batch T = bpool.get(), X = bpool.get();
+        const unsigned all = qmg::full_mask(nb);
+        for (int j = 0; j < nb; j++) {
+          if (i == 0) copy_vector(T.vec(j), test_vectors[fine_idx][j], n);
+          else { zero_vector(T.vec(j), n); mg_object->get_transfer(fine_idx - 1)->restrict_f2c(test_vectors[fine_idx - 1][j], T.vec(j)); }
+        }
+        qmg::bzero(X, n, all);
+        inversion_verbose_struct vq(VERB_NONE, "");
+        std::vector<inversion_info> binv = bgcr_core(X, T, (int)n, 10, 1e-10, -1, apply_stencil_2D_M_batch, (void*)mg_object->get_stencil(fine_idx),
+                                                     mg_preconditioner_batch, (void*)&bk, all, true, &vq, "VPGCR");
+        for (int j = 0; j < nb; j++) {
+          copy_vector(test_vectors[fine_idx][j], X.vec(j), n);
+          mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, binv[j].ops_count + 1, fine_idx);
+          cout << "[QMG-SETUP]: pass " << m << " level " << fine_idx << " test vector " << j << ": " << binv[j].iter << " K-cycle iterations, residual "
+               << sqrt(binv[j].resSq) << ", t = " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count() << " s (batched)" << std::endl;
+        }
+      }
       for (int j = 0; j < coarse_dof / 2; j++) {
         null_vectors[j] = allocate_vector<complex<double>>(n);
         null_vectors[j + coarse_dof / 2] = allocate_vector<complex<double>>(n);
-        complex<double>* temp_rand = mg_object->get_storage(fine_idx)->check_out();
-        if (i == 0) copy_vector(temp_rand, test_vectors[fine_idx][j], n);
-        else { zero_vector(temp_rand, n); mg_object->get_transfer(fine_idx - 1)->restrict_f2c(test_vectors[fine_idx - 1][j], temp_rand); }
-        zero_vector(test_vectors[fine_idx][j], n);
-        // 10 iterations of the current K-cycle on this level (n22:373-376); n22 itself uses the ORIGINAL operator here
-        invif = minv_vector_gcr_var_precond(test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, apply_stencil_2D_M, (void*)mg_object->get_stencil(fine_idx),
-                                            schur ? (precond_op_cplx)0 : StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
-        mg_object->get_storage(fine_idx)->check_in(temp_rand);
-        mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count + 1, fine_idx);
-        cout << "[QMG-SETUP]: pass " << m << " level " << fine_idx << " test vector " << j << ": " << invif.iter << " K-cycle iterations, residual "
-             << sqrt(invif.resSq) << ", t = " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count() << " s" << std::endl;
+        if (!batched_setup) {
+          complex<double>* temp_rand = mg_object->get_storage(fine_idx)->check_out();
+          if (i == 0) copy_vector(temp_rand, test_vectors[fine_idx][j], n);
+          else { zero_vector(temp_rand, n); mg_object->get_transfer(fine_idx - 1)->restrict_f2c(test_vectors[fine_idx - 1][j], temp_rand); }
+          zero_vector(test_vectors[fine_idx][j], n);
+          // 10 iterations of the current K-cycle on this level (n22:373-376); n22 itself uses the ORIGINAL operator here
+          invif = minv_vector_gcr_var_precond(test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, apply_stencil_2D_M, (void*)mg_object->get_stencil(fine_idx),
+                                              schur ? (precond_op_cplx)0 : StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
+          mg_object->get_storage(fine_idx)->check_in(temp_rand);
+          mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count + 1, fine_idx);
+          cout << "[QMG-SETUP]: pass " << m << " level " << fine_idx << " test vector " << j << ": " << invif.iter << " K-cycle iterations, residual "
+               << sqrt(invif.resSq) << ", t = " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count() << " s" << std::endl;
+        }
         zero_vector(null_vectors[j], n);
         zero_vector(null_vectors[j + coarse_dof / 2], n);
         for (int k = 0; k < j; k++) orthogonal(test_vectors[fine_idx][j], test_vectors[fine_idx][k], n);

@@ -20,6 +20,7 @@
 #define QMG_BATCH_HPP
 
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include <vector>
 

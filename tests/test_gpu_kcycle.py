@@ -137,3 +137,23 @@ def test_batched_kcycle_reproduces_the_single_solves(golden_dir, L, n_refine, co
     for _, single_it, batch_it, diff in ver:
         assert abs(int(single_it) - int(batch_it)) <= 1
         assert float(diff) < 1e-7
+
+
+def test_n22_four_levels_and_batched_setup(golden_dir):
+    """BASELINE configs[4] shape (four levels) at 256^2 -> 64^2 -> 16^2 -> 4^2 on the tiled l64 config.  The reference's
+    build_coarse_by_restrict declares no doubling type (n22:682), which leaves every 'down' null vector of the third
+    transfer zero and the hierarchy NaN; the driver declares it (see its comment).  Also: the adaptive relaxations of a
+    level run as one lock-step batch -- the sequential setup (QMG_NO_BATCHED_SETUP) must give the same solve."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    cmd = [os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "3", "1", gauge_file, "64"]
+    res = {}
+    for tag, extra in (("batched", {}), ("sequential", {"QMG_NO_BATCHED_SETUP": "1"})):
+        out = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", **extra), capture_output=True, text=True, timeout=150)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "nan" not in out.stdout.lower()
+        assert out.stdout.count("[QMG-OPS-STATS]") == 4
+        res[tag] = (int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1)), float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1)),
+                    ("(batched)" in out.stdout))
+    assert res["batched"][2] and not res["sequential"][2]
+    assert res["batched"][1] <= 1.05e-10 and res["sequential"][1] <= 1.05e-10
+    assert abs(res["batched"][0] - res["sequential"][0]) <= 1
