@@ -90,6 +90,7 @@ const char* qmg_last_hip_error(void);
 const char* qmg_version(void);
 int qmg_malloc(void** dev_ptr, size_t bytes);   /* replaces allocate_vector<T> for device arrays */
 int qmg_free(void* dev_ptr);
+int qmg_mem_info(size_t* free_bytes, size_t* total_bytes);   /* HBM free / total on the current device: batch sizing */
 int qmg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);  /* synchronous when stream == NULL */
 int qmg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int qmg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);

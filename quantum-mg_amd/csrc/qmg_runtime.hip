@@ -61,6 +61,14 @@ int qmg_free(void* p) {
   return QMG_SUCCESS;
 }
 
+int qmg_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  size_t f = 0, t = 0;
+  QMG_HIP_CHECK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return QMG_SUCCESS;
+}
+
 static int do_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, void* stream) {
   if (bytes == 0) return QMG_SUCCESS;
   if (!dst || !src) return QMG_ERR_INVALID;

@@ -1,0 +1,113 @@
+// mrhs_solve.hpp -- the batched outer solve shared by n13_wilson_kcycle_mrhs and n22_wilson_kcycle_adaptive (nrhs=K):
+// nrhs gaussian right-hand sides (seeds seed, seed+1, ...), solved in lock-step batches (include/qmg/batch.hpp) sized to
+// the HBM that is free (qmg::batch_systems_that_fit), per-system report, and optionally the same systems re-solved alone
+// by the single-vector path.
+#ifndef MRHS_SOLVE_HPP
+#define MRHS_SOLVE_HPP
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../include/qmg/qmg.hpp"
+
+// verify_mode: 0 none, 1 every system, 2 system 0 only.  Returns true when every system converged (and verified).
+inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int nrhs, unsigned long long seed, double tol, int max_iter, int restart_freq,
+                                  bool quiet, int verify_mode, double setup_s, void (*print_ops_stats)(void*), void* stats_arg) {
+  using namespace std;
+  if (nrhs < 1) { std::cout << "[QMG-ERROR]: nrhs must be positive\n"; return false; }
+  const size_t n = (size_t)lat0->get_size_cv_l();
+  {
+    BatchKcycle probe(mg, 1);
+    if (!probe.supported()) { std::cout << "[QMG-ERROR]: the batched K-cycle implements the ORIGINAL-operator configuration only.\n"; return false; }
+  }
+  // batch size: what fits (an outer solve rarely needs its whole restart length; 48 directions is a safe expectation for
+  // these K-cycles, and bgcr_core stops loudly if a basis vector cannot be allocated)
+  const int per_batch = qmg::batch_systems_that_fit(mg, std::min(restart_freq > 0 ? restart_freq : max_iter, 48), std::min(nrhs, qmg::BATCH_MAX));
+  cout << "[QMG-MRHS]: " << nrhs << " systems in lock-step batches of " << per_batch << "\n";
+
+  inversion_verbose_struct verb;
+  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verb_prefix = "Level 0: ";
+  verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.precond_verb_prefix = "Prec ";
+
+  bool ok_ = true;
+  long total_iters = 0;
+  double solve_s = 0.0, single_s = 0.0, worst = 0.0;
+  int max_diff_iter = 0, nver = 0;
+  cout << setprecision(12);
+  for (int k0 = 0; k0 < nrhs; k0 += per_batch) {
+    const int nb = std::min(per_batch, nrhs - k0);
+    const unsigned all = qmg::full_mask(nb);
+    BatchKcycle bk(mg, nb);
+    std::vector<inversion_info> inv;
+    std::vector<double> bsq, rsq;
+    {
+      qmg::BatchPool pool(n, nb);
+      qmg::Batch b = pool.get(), x = pool.get(), Ax = pool.get();
+      if (b.p == 0 || x.p == 0 || Ax.p == 0) { std::cout << "[QMG-ERROR]: out of device memory for a batch of " << nb << " systems\n"; return false; }
+      for (int k = 0; k < nb; k++) gaussian(b.vec(k), n, seed + (unsigned long long)(k0 + k));
+      if (getenv("QMG_MRHS_POINT") && k0 == 0 && nb > 1) {   // test hook: system 1 becomes a point source, which converges on its own schedule
+        zero_vector(b.vec(1), n);
+        qmg::set_element(b.vec(1), 5, complex<double>(1.0, 0.0));
+      }
+      bsq = qmg::bnorm2sq(b, n, all);
+      qmg::bzero(x, n, all);
+      qmg_stream_sync(0);
+      auto t0 = std::chrono::steady_clock::now();
+      inv = bgcr_core(x, b, (int)n, max_iter, tol, restart_freq, apply_stencil_2D_M_batch, (void*)mg->get_stencil(0), mg_preconditioner_batch, (void*)&bk, all, true,
+                      &verb, "VPGCR-restart");
+      qmg_stream_sync(0);
+      solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      apply_stencil_2D_M_batch(Ax, x, all, (void*)mg->get_stencil(0));
+      rsq = qmg::bdiffnorm2sq(b, Ax, n, all);
+      for (int k = 0; k < nb; k++) {
+        const double true_res = sqrt(rsq[k] / bsq[k]);
+        cout << "[QMG-MRHS]: rhs " << k0 + k << " " << (inv[k].success ? "converged" : "failed to converge") << " in " << inv[k].iter << " iterations ; alleged tolerance "
+             << sqrt(inv[k].resSq / bsq[k]) << " ; check tolerance " << true_res << "\n";
+        ok_ = ok_ && inv[k].success && true_res < 10 * tol;
+        total_iters += inv[k].iter;
+      }
+      if (verify_mode != 0) {   // the same systems, alone, through the single-vector path
+        inversion_verbose_struct vq(VERB_NONE, "");
+        complex<double>* x1 = mg->check_out(0);
+        for (int k = 0; k < nb; k++) {
+          if (verify_mode == 2 && k0 + k > 0) break;
+          zero_vector(x1, n);
+          qmg_stream_sync(0);
+          auto t1 = std::chrono::steady_clock::now();
+          inversion_info i1 = minv_vector_gcr_var_precond_restart(x1, b.vec(k), (int)n, max_iter, tol, restart_freq, apply_stencil_2D_M, (void*)mg->get_stencil(0),
+                                                                  StatefulMultigridMG::mg_preconditioner, (void*)mg, &vq);
+          qmg_stream_sync(0);
+          const double t_single = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+          single_s += t_single;
+          nver++;
+          const double diff = sqrt(diffnorm2sq(x1, x.vec(k), n) / norm2sq(x1, n));
+          cout << "[QMG-MRHS-VERIFY]: rhs " << k0 + k << " single-path iterations " << i1.iter << " (batched " << inv[k].iter << ") ; relative solution difference " << diff
+               << " ; single-path solve " << t_single << " s\n";
+          worst = std::max(worst, diff);
+          max_diff_iter = std::max(max_diff_iter, std::abs(i1.iter - inv[k].iter));
+          ok_ = ok_ && i1.success;
+        }
+        mg->check_in(x1, 0);
+      }
+    }
+    qmg::VecPool::release_all();   // the next batch may have a different size
+  }
+  if (print_ops_stats) print_ops_stats(stats_arg);
+  cout << "[QMG-TIMING]: setup " << setup_s << " s ; batched solve of " << nrhs << " systems " << solve_s << " s ; aggregate outer iterations/s " << total_iters / solve_s
+       << " ; systems/s " << nrhs / solve_s << "\n";
+  if (nver > 0) {
+    cout << "[QMG-MRHS-VERIFY]: worst relative solution difference " << worst << " ; largest iteration-count difference " << max_diff_iter << " ; one-at-a-time solves "
+         << single_s * nrhs / nver << " s" << (nver < nrhs ? " (extrapolated)" : "") << " vs batched " << solve_s << " s = " << (single_s * nrhs / nver) / solve_s << "x\n";
+    // both solve to 1e-10: solutions agree to cond(A) * 1e-10
+    ok_ = ok_ && worst < 1e-6 && max_diff_iter <= 1;
+  }
+  return ok_;
+}
+
+#endif

@@ -1,6 +1,6 @@
 // n22_wilson_kcycle_adaptive -- the build's counterpart of
 // tests/n22_wilson_kcycle_adaptive/wilson_kcycle.cpp on the GPU: adaptive multigrid setup, then the n13 solve.
-//   ./n22_wilson_kcycle_adaptive L mass beta n_refine n_setup [gauge_file] [tile] [solve_type]
+//   ./n22_wilson_kcycle_adaptive L mass beta n_refine n_setup [gauge_file] [tile] [solve_type | nrhs=K]
 // Setup (n22:230-426):
 //   * initial hierarchy: per level, coarse_dof/2 gaussian vectors relaxed by 10 Richardson iterations
 //     (omega 0.33, n22:289, 664), Gram-Schmidt + normalise, chiral doubling, TransferMG (block-ortho x2),
@@ -25,6 +25,7 @@
 #include <string>
 
 #include "../include/qmg/qmg.hpp"
+#include "mrhs_solve.hpp"
 
 using namespace std;
 
@@ -95,6 +96,8 @@ int main(int argc, char** argv) {
   const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
   const int tile = (argc > 7) ? stoi(argv[7]) : 64;
   const bool schur = (argc > 8) && string(argv[8]) == "schur";
+  // "nrhs=K" (not in n22): after the reference's single solve, K more gaussian systems are solved in one lock-step batch
+  const int nrhs_batched = (argc > 8 && string(argv[8]).rfind("nrhs=", 0) == 0) ? stoi(string(argv[8]).substr(5)) : 0;
   const bool quiet = getenv("QMG_QUIET") != 0;
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4, coarse_dof = 8;
@@ -302,7 +305,9 @@ int main(int argc, char** argv) {
   cout << setprecision(6) << "[QMG-TIMING]: setup " << setup_s << " s ; solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
   mg_object->check_in(x_rec, 0); mg_object->check_in(b_prep, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
 
-  const bool ok_ = invif.success && true_res < 20 * tol;
+  bool ok_ = invif.success && true_res < 20 * tol;
+  if (nrhs_batched > 0)
+    ok_ = mrhs_solve_and_report(mg_object, lats[0], nrhs_batched, g_seed, tol, max_iter, restart_freq, quiet, getenv("QMG_MRHS_VERIFY") ? 1 : 0, setup_s, 0, 0) && ok_;
   delete mg_object;
   for (int i = 0; i < n_refine; i++) {
     delete transfer_objs[i]; delete level_solve_objs[i];

@@ -119,6 +119,30 @@ inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<Batch>& x
 
 }  // namespace qmg
 
+namespace qmg {
+// How many systems of a K-cycle solve fit in the HBM that is free right now.  Per system the outer flexible GCR keeps
+// 2 (restart or expected iterations) + ~8 vectors of level 0, every intermediate GCR 2 restart + ~12 of its level, and
+// the coarsest GCR 2 restart + 4; 15 % head-room.  (4096^2 Wilson, restart 64: ~75 GB per system -- 3 per 288 GB GPU.)
+inline int batch_systems_that_fit(StatefulMultigridMG* mg, int outer_basis, int want) {
+  size_t free_b = 0, total_b = 0;
+  VecPool::release_all();   // give cached scratch of other lengths back first
+  if (qmg_mem_info(&free_b, &total_b) != QMG_SUCCESS) return 1;
+  double per_system = 0.0;
+  const int nl = mg->get_num_levels();
+  for (int i = 0; i < nl; i++) {
+    int basis = outer_basis;
+    if (i > 0 && i < nl - 1) { const int rf = mg->get_level_solve(i)->intermediate_restart_freq, it = mg->get_level_solve(i)->intermediate_iters; basis = (rf > 0 && rf < it) ? rf : it; }
+    if (i == nl - 1 && nl > 1) { const int rf = mg->get_coarsest_solve()->coarsest_restart_freq, it = mg->get_coarsest_solve()->coarsest_iters; basis = (rf > 0 && rf < it) ? rf : it; }
+    per_system += (2.0 * basis + 12.0) * (double)mg->get_lattice(i)->get_size_cv_l() * 16.0;
+  }
+  int fit = (int)(0.85 * (double)free_b / per_system);
+  if (fit < 1) fit = 1;
+  if (fit > want) fit = want;
+  if (fit > BATCH_MAX) fit = BATCH_MAX;
+  return fit;
+}
+}  // namespace qmg
+
 // lhs_k = A rhs_k for the active systems
 typedef void (*batch_matrix_op)(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data);
 typedef void (*batch_precond_op)(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb);
@@ -243,6 +267,10 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
     if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(std::vector<double>(nrhs, 0.0)); }
     for (int k = 0; k < nrhs; k++) { if ((int)C[k].size() <= kb) { C[k].push_back(qmg::cvec()); alphas[k].push_back(0.0); } }
     qmg::Batch z = Z[kb], w = W[kb];
+    if (z.p == 0 || w.p == 0 || r.p == 0 || tmp.p == 0) {   // out of HBM: stop, report every active system as not converged
+      std::cout << "[QMG-ERROR]: " << name << ": could not allocate basis vector " << kb << " for a batch of " << nrhs << " systems; size the batch with qmg::batch_systems_that_fit.\n";
+      break;
+    }
     if (precond) { qmg::bzero(z, size, act); precond(z, r, size, act, precond_info, &pverb); }
     else qmg::bcopy(z, r, size, act);
     matrix_vector(w, z, act, extra_info);
