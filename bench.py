@@ -259,6 +259,28 @@ def kcycle_c3_batched(nrhs=8):
         return {"error": repr(e)}
 
 
+def kcycle_c5_shape():
+    """BASELINE configs[4] shape on one GPU in fp64: the adaptive n22 K-cycle, 4096^2 -> 1024^2 -> 256^2 -> 64^2, nc = 8,
+    one adaptive pass, the reference's ORIGINAL-operator mode (its fp32 / red-black / 8-GPU qualifiers are not built)."""
+    import re
+    import subprocess
+    drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+    exe = os.path.join(drivers, "n22_wilson_kcycle_adaptive")
+    fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
+    try:
+        p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
+                           capture_output=True, text=True, timeout=600)
+        m = re.search(r"setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
+        it = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
+        res = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
+        return {"workload": "adaptive Wilson K-cycle (n22 parameters, 1 adaptive pass), 4096x4096, 4 levels, coarse nc=8, fp64, 1 GPU",
+                "metric": "outer VPGCR iterations per second", "value": float(m.group(3)), "outer_iterations": int(it.group(2)),
+                "converged": it.group(1) == "converged", "true_residual": float(res.group(1)), "solve_s": float(m.group(2)), "setup_s": float(m.group(1)),
+                "returncode": p.returncode}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,6 +386,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_also and not args.no_kcycle:
         out["also_kcycle"] = kcycle_c3()
         out["also_kcycle_batched"] = kcycle_c3_batched()
+        out["also_kcycle_c5_shape"] = kcycle_c5_shape()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fixture)

@@ -157,4 +157,19 @@ sod = ol.make_desc(scL, scL, cnc, socl, soho, -0.07)
 row("coarse apply_M nc=24, 512^2", "coarse.h + stencil_2d.h:912", timeit(lambda: qmg.stencil_apply(cdsc, cy, cv), reps=10), 46848 * cL * cL, 23232 * cL * cL,
     cpu_time(lambda: ol.stencil_apply(sod, sc)), (cL / scL) ** 2)
 
+# ---------------- lock-step batches: the coarse apply on the f64 matrix cores, batched transfer
+for k in (8, 16):
+    xb, yb = gauss(k * csize, 20 + k), qmg.DeviceArray(k * csize)
+    row("coarse apply_M nc=24, 512^2, %d rhs per launch (MFMA)" % k, "qmg_stencil_apply_batch (kernel C)",
+        timeit(lambda: qmg.stencil_apply_batch(cdsc, yb, xb, qmg.P_ALL | qmg.P_ZERO, k, csize, (1 << k) - 1), reps=10), (5 * cnc * cnc + 2 * cnc * k) * 16 * cL * cL,
+        (8 * cnc * cnc * 5 + 8 * cnc) * cL * cL * k, note="%.3f of the one-rhs kernel's bytes per right-hand side" % ((5 * cnc * cnc / k + 2 * cnc) / (5 * cnc * cnc + 2 * cnc)))
+    xb.free(); yb.free()
+nv = gauss(cnc * fsize, 5)
+k = 8
+fb, cb = gauss(k * fsize, 31), gauss(k * csize, 32)
+row("prolong_c2f, 8 systems per pass", "qmg_prolong_batch", timeit(lambda: qmg.prolong_batch(nv, cnc, cb, fb, fd, cd, k, csize, fsize, 255), reps=5),
+    (cnc * fsize + 2 * k * fsize + k * csize) * C, 8 * cnc * fsize * k)
+row("restrict_f2c, 8 systems per pass", "qmg_restrict_batch", timeit(lambda: qmg.restrict_batch(nv, cnc, fb, cb, fd, cd, k, fsize, csize, 255), reps=5),
+    (cnc * fsize + k * fsize + 2 * k * csize) * C, 8 * cnc * fsize * k)
+
 print(json.dumps({"device": "MI355X (gfx950)", "hbm_peak_GBps": PEAK, "rows": rows}, indent=1))
