@@ -121,6 +121,14 @@ int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, uns
 int qmg_stencil_apply_batch(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                             int nrhs, size_t vec_stride, unsigned mask, void* stream);
 
+/* OPT-IN storage format: d->clover / d->hopping point to complex<float> copies of the matrices (qmg_c64_to_c32); vectors,
+ * shifts and all arithmetic stay fp64.  Halves the matrix stream of an HBM-bound coarse apply.  Meant for operators that
+ * only precondition (the K-cycle inside a flexible fp64 outer solver); parity: equal to 1e-13 to the fp64 apply of the
+ * ROUNDED matrices.  nc = 1, 2, 4 return QMG_ERR_UNSUPPORTED.  nrhs <= 16, mask as in qmg_stencil_apply_batch. */
+int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                            int nrhs, size_t vec_stride, unsigned mask, void* stream);
+int qmg_c64_to_c32(void* dst_f32, const void* src_f64, size_t n, void* stream);
+
 /* ---------------- operator construction from U(1) links (device side) ---------------- */
 /* gauge: nc=1 LatticeGauge (mu,eo,y,x), 2*Lx*Ly complex. */
 int qmg_wilson_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, double wilson_coeff, void* stream); /* wilson.h:153-209 */

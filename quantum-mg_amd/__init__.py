@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "qmg_malloc", "qmg_free", "qmg_mem_info", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
     "qmg_stream_create", "qmg_stream_destroy", "qmg_stream_sync",
     "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms",
-    "qmg_cshift", "qmg_stencil_apply", "qmg_stencil_apply_batch", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
+    "qmg_cshift", "qmg_stencil_apply", "qmg_stencil_apply_batch", "qmg_stencil_apply_mat32", "qmg_c64_to_c32", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
     "qmg_build_dagger", "qmg_build_rbjacobi", "qmg_cmat_conjtrans",
     "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",
     "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
@@ -342,6 +342,15 @@ def _coef(a, nrhs):
 def stencil_apply_batch(desc, lhs, rhs, pieces, nrhs, vec_stride, mask, stream=None):
     check(lib().qmg_stencil_apply_batch(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
           "qmg_stencil_apply_batch")
+
+
+def stencil_apply_mat32(desc, lhs, rhs, pieces, nrhs, vec_stride, mask, stream=None):
+    check(lib().qmg_stencil_apply_mat32(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
+          "qmg_stencil_apply_mat32")
+
+
+def c64_to_c32(dst, src, n):
+    check(lib().qmg_c64_to_c32(_vp(dst), _vp(src), C.c_size_t(n), None), "qmg_c64_to_c32")
 
 
 def batch_blas(op, z, n, nrhs, stride, mask, a=None, b=None, x=None, y=None):

@@ -226,6 +226,14 @@ __global__ __launch_bounds__(BLOCK) void k_identity_cm(cplx* __restrict__ out, l
   }
 }
 
+// complex<double> -> complex<float> (round to nearest): the opt-in fp32 matrix storage of qmg_stencil_apply_mat32
+__global__ __launch_bounds__(BLOCK) void k_c64_to_c32(float2* __restrict__ dst, const cplx* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const cplx v = src[i];
+    dst[i] = make_float2((float)v.x, (float)v.y);
+  }
+}
+
 }  // namespace qmg
 
 using namespace qmg;
@@ -339,3 +347,11 @@ int qmg_build_rbjacobi(void* cinv, void* rb_clover, void* rb_hopping, const qmg_
 }
 
 }  // extern "C"
+
+extern "C" int qmg_c64_to_c32(void* dst_f32, const void* src_f64, size_t n, void* stream) {
+  if ((!dst_f32 || !src_f64) && n) return QMG_ERR_INVALID;
+  if (n == 0) return QMG_SUCCESS;
+  qmg::k_c64_to_c32<<<qmg::grid_1d(n), qmg::BLOCK, 0, qmg::as_stream(stream)>>>((float2*)dst_f32, (const qmg::cplx*)src_f64, (long)n);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}

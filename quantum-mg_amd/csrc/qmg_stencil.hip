@@ -48,6 +48,7 @@ struct StencilArgs {
   double shift[2], eo_shift[2], dof_shift[2];
   unsigned char ridx[16];   // masked batches (qmg_stencil_apply_batch): right-hand side processed as column k; else unused
   int use_idx;       // 0: column k is right-hand side k
+  int mat32;         // 1: clover / hopping point to complex<float> arrays (qmg_stencil_apply_mat32; kernels B and C only)
   int ablate;        // diagnostic builds only (tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 };
 
@@ -62,6 +63,38 @@ __device__ __forceinline__ cplx ld(const cplx* p) {
     return v;
   }
   return *p;
+}
+
+// matrix element i of a complex<double> (M32 = false) or complex<float> (M32 = true) array, widened to fp64
+template <bool M32, bool NT>
+__device__ __forceinline__ cplx ldm(const cplx* base, long i) {
+  if (M32) {
+    const float2* p = reinterpret_cast<const float2*>(base) + i;
+    float2 v;
+    if (NT) {
+      const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long*>(p));
+      v.x = __int_as_float((int)(raw & 0xFFFFFFFFll));
+      v.y = __int_as_float((int)(raw >> 32));
+    } else v = *p;
+    return make_double2((double)v.x, (double)v.y);
+  }
+  return ld<NT>(base + i);
+}
+
+// two consecutive complex<float> matrix elements (16 B, element index i even) widened to fp64
+template <bool NT>
+__device__ __forceinline__ void ldm32_pair(const cplx* base, long i, cplx& v0, cplx& v1) {
+  const double* p = reinterpret_cast<const double*>(reinterpret_cast<const float2*>(base) + i);   // 16-B aligned for even i
+  long long r0, r1;
+  if (NT) {
+    r0 = __builtin_nontemporal_load(reinterpret_cast<const long long*>(p));
+    r1 = __builtin_nontemporal_load(reinterpret_cast<const long long*>(p) + 1);
+  } else {
+    const double2 d = *reinterpret_cast<const double2*>(p);
+    r0 = __double_as_longlong(d.x); r1 = __double_as_longlong(d.y);
+  }
+  v0 = make_double2((double)__int_as_float((int)(r0 & 0xFFFFFFFFll)), (double)__int_as_float((int)(r0 >> 32)));
+  v1 = make_double2((double)__int_as_float((int)(r1 & 0xFFFFFFFFll)), (double)__int_as_float((int)(r1 >> 32)));
 }
 
 template <bool NT>
@@ -299,7 +332,7 @@ struct GenLayout {
 
 constexpr int GEN_MAX_PER_THREAD = 12;   // register-staged matrix elements per thread per piece
 
-template <int PT>
+template <int PT, bool M32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* mlds = reinterpret_cast<cplx*>(smem_raw);                    // [S*nc rows][rs]
@@ -343,26 +376,40 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 
       // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
       const int order[5] = {4, 0, 1, 2, 3};
-      cplx stage[PT];
+      // fp32-stored matrices with even nc: a lane loads PAIRS of elements (16 B per load, as in the fp64 stream) -- with 8-B
+      // loads the same number of load instructions moved half the bytes and the apply got no faster
+      constexpr int PTS = PT + (PT & 1);
+      const bool pairs = M32 && !(nc & 1);
+      cplx stage[PTS];
       cplx xstage = cmake(0.0, 0.0);
       int cur = -1;
       // find first active piece and prefetch it
       int oi = 0;
       while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
       auto prefetch = [&](int piece) {
-        const cplx* msrc = (piece == 4) ? a.clover + site0 * nc2 : a.hopping + (long)piece * a.size_cm + site0 * nc2;
+        const cplx* mbase = (piece == 4) ? a.clover : a.hopping;                 // (element offsets, so that the same
+        long moff = (piece == 4) ? site0 * nc2 : (long)piece * a.size_cm + site0 * nc2;   //  code serves both matrix widths)
         if ((a.ablate & 16) && (piece == 2 || piece == 3)) {
           // diagnostic (wrong arithmetic, right access pattern): what the backward hops would cost if they re-read the
           // neighbour's FORWARD link (gamma5-hermitian link compression) instead of streaming their own array
           long nsite0 = (piece == 2) ? opp + (long)y * a.hr + (j0 + s - 1 < 0 ? 0 : j0 + s - 1) : opp + (long)ym * a.hr + j0;
           if (nsite0 + nsite > 2 * a.half_vol) nsite0 = 2 * a.half_vol - nsite;
-          msrc = a.hopping + (long)(piece - 2) * a.size_cm + nsite0 * nc2;
+          moff = (long)(piece - 2) * a.size_cm + nsite0 * nc2;
         }
         const int lim = nsite * (int)nc2;
+        if (pairs) {
 #pragma unroll
-        for (int q = 0; q < PT; q++) {
-          const int el = tid + q * BLOCK;
-          stage[q] = (el < lim) ? msrc[el] : cmake(0.0, 0.0);
+          for (int q = 0; q < PTS / 2; q++) {
+            const int el = 2 * (tid + q * BLOCK);
+            if (el < lim) ldm32_pair<false>(mbase, moff + el, stage[2 * q], stage[2 * q + 1]);
+            else { stage[2 * q] = cmake(0.0, 0.0); stage[2 * q + 1] = cmake(0.0, 0.0); }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PT; q++) {
+            const int el = tid + q * BLOCK;
+            stage[q] = (el < lim) ? ldm<M32, false>(mbase, moff + el) : cmake(0.0, 0.0);
+          }
         }
         // neighbour vector element for (site, c) = tid / nc, tid % nc
         if (tid < nsite * nc) {
@@ -382,12 +429,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
       while (cur >= 0) {
         __syncthreads();   // previous compute finished reading LDS
         // registers -> LDS (padded rows)
+        if (pairs) {
 #pragma unroll
-        for (int q = 0; q < PT; q++) {
-          const int el = tid + q * BLOCK;
-          if (el < L.mat_elems) {
-            const int rowi = el / nc, cc = el - rowi * nc;
-            mlds[(size_t)rowi * L.rs + cc] = stage[q];
+          for (int q = 0; q < PTS / 2; q++) {
+            const int el = 2 * (tid + q * BLOCK);
+            if (el < L.mat_elems) {   // (mat_elems and nc even: the pair never straddles a row)
+              const int rowi = el / nc, cc = el - rowi * nc;
+              mlds[(size_t)rowi * L.rs + cc] = stage[2 * q];
+              mlds[(size_t)rowi * L.rs + cc + 1] = stage[2 * q + 1];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PT; q++) {
+            const int el = tid + q * BLOCK;
+            if (el < L.mat_elems) {
+              const int rowi = el / nc, cc = el - rowi * nc;
+              mlds[(size_t)rowi * L.rs + cc] = stage[q];
+            }
           }
         }
         if (tid < L.S * nc) xlds[tid] = xstage;
@@ -397,11 +456,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
         while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
         if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
         __syncthreads();
-        if (worker && s_of < nsite) {
+        if (worker && s_of < nsite && !(a.ablate & 32)) {
           const cplx* mrow = mlds + (size_t)sr * L.rs;
           const cplx* xs = xlds + s_of * nc;
           for (int cc = c0; cc < c1; cc++) cmac(acc, mrow[cc], xs[cc]);
         }
+        if (a.ablate & 32) acc = cadd(acc, stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
         cur = nxt;
       }
 
@@ -461,7 +521,7 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // at 512^2, nc = 24, 16 rhs: the extra f64 adds and the third accumulator cost more than the saved MFMA -- and dropped.)
 // The f64 matrix pipe sustains 48 TFLOP/s on this part (tools/mfma_f64_rate.hip), which at nc = 24 is 2.7 ms of plain
 // MFMA work per 512^2 apply against 2.4 ms of HBM time -- the MFMA count, not the byte count, is what MODE 1 cuts.
-template <int NC, int MODE>
+template <int NC, int MODE, bool M32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, const int nk) {
   constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
   constexpr int NACC = 2;
@@ -503,15 +563,26 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 #pragma unroll
       for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    cplx G[NG];
+    constexpr int NGP = (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS per lane per piece (fp32-stored matrices)
+    cplx G[M32 ? 2 * NGP : NG];
     // MODE 1 needs only the half of X its column carries (re for columns 0-7, im for 8-15): one double per k-step
     typename std::conditional<MODE == 1, double, cplx>::type B[2][KS];
     auto load_piece = [&](int pc, int set) {      // global -> registers: matrix (lane-linear) and the k right-hand sides
-      const cplx* m = ((pc == 0) ? a.clover : a.hopping + (long)(pc - 1) * a.size_cm) + site * NC2;
+      const cplx* mbase = (pc == 0) ? a.clover : a.hopping;
+      const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * NC2;
+      if (M32) {   // pairs of complex<float>: 16 B per lane per load
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        const int el = g * WAVE + lane;
-        G[g] = (NC2 % WAVE == 0 || el < NC2) ? ld<true>(m + el) : cmake(0.0, 0.0);
+        for (int g = 0; g < NGP; g++) {
+          const int el = 2 * (g * WAVE + lane);
+          if (NC2 % (2 * WAVE) == 0 || el < NC2) ldm32_pair<true>(mbase, moff + el, G[2 * g], G[2 * g + 1]);
+          else { G[2 * g] = cmake(0.0, 0.0); G[2 * g + 1] = cmake(0.0, 0.0); }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          const int el = g * WAVE + lane;
+          G[g] = (NC2 % WAVE == 0 || el < NC2) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
+        }
       }
       const cplx* x = a.rhs + koff + nb[pc] * NC;
 #pragma unroll
@@ -524,10 +595,18 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
     };
     auto park_piece = [&]() {                     // registers -> this wavefront's LDS slice, padded rows
       wave_lds_handoff();                         // the previous piece's fragment reads are done
+      if (M32) {
 #pragma unroll
-      for (int g = 0; g < NG; g++) {
-        const int el = g * WAVE + lane;
-        if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[g];
+        for (int g = 0; g < NGP; g++) {
+          const int el = 2 * (g * WAVE + lane);
+          if (NC2 % (2 * WAVE) == 0 || el < NC2) { mlds[(el / NC) * RS + (el % NC)] = G[2 * g]; mlds[(el / NC) * RS + (el % NC) + 1] = G[2 * g + 1]; }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          const int el = g * WAVE + lane;
+          if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[g];
+        }
       }
       wave_lds_handoff();
     };
@@ -609,12 +688,15 @@ static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
-static GenLayout make_gen_layout(int nc, int hr) {
+static GenLayout make_gen_layout(int nc, int hr, int mat32) {
   GenLayout L;
   const int nc2 = nc * nc;
   int S = (BLOCK * GEN_MAX_PER_THREAD) / nc2;       // registers: S*nc^2 <= 256*12
   if (S > BLOCK / nc) S = BLOCK / nc;               // one (s,r) row per thread at least
   if (S > hr) S = hr;
+  // fp32-stored matrices: the kernel is bound by bytes in flight per CU (one piece per resident block), not by HBM; with
+  // half the bytes per piece, smaller tiles (more resident blocks) pay: 512^2, nc = 24: S = 5 1.81 ms, S = 2 1.59 ms
+  if (mat32 && nc >= 16 && S > 2) S = 2;
   if (g_gen_sites > 0 && S > g_gen_sites) S = g_gen_sites;
   if (S < 1) S = 1;
   L.S = S;
@@ -644,7 +726,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream);
+                              const unsigned char* ridx, void* stream, int mat32 = 0);
 
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
@@ -665,8 +747,24 @@ extern "C" int qmg_stencil_apply_batch(const qmg_stencil_desc* d, void* lhs, con
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream);
 }
 
+// Matrices stored as complex<float> (d->clover / d->hopping point to float pairs), everything else fp64: vectors, shifts,
+// accumulation.  Halves the matrix stream of the HBM-bound coarse applies.  An OPT-IN storage format for operators that
+// only precondition (the K-cycle inside a flexible fp64 outer solver); nc = 1, 2, 4 are not served.
+extern "C" int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                                       int nrhs, size_t vec_stride, unsigned mask, void* stream) {
+  if (!d || d->nc == 1 || d->nc == 2 || d->nc == 4) return QMG_ERR_UNSUPPORTED;
+  if (nrhs < 1 || nrhs > 16) return QMG_ERR_INVALID;
+  unsigned char ridx[16];
+  int n = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
+  if (n == 0) return QMG_SUCCESS;
+  if (n == nrhs) return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 1);
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1);
+}
+
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream) {
+                              const unsigned char* ridx, void* stream, int mat32) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -685,6 +783,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.nrhs = nrhs;
   a.vec_stride = (long)vec_stride;
   a.use_idx = ridx ? 1 : 0;
+  a.mat32 = mat32;
   for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
   a.ablate = g_stencil_ablate;
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
@@ -754,13 +853,15 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
       const size_t smem = sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
       const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
+#define QMG_MFMA_LAUNCH1(NC, MODE, M32)                                                                         \
+      {                                                                                                         \
+        if (smem > 64 * 1024)                                                                                   \
+          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        k_stencil_mfma<NC, MODE, M32><<<grid, block, smem, st>>>(b, nk);                                        \
+      }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
-      if (smem > 64 * 1024) {                                                                                   \
-        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-      }                                                                                                         \
-      if (mode == 0) k_stencil_mfma<NC, 0><<<grid, block, smem, st>>>(b, nk);                                   \
-      else k_stencil_mfma<NC, 1><<<grid, block, smem, st>>>(b, nk);
+      if (mode == 0) { if (a.mat32) QMG_MFMA_LAUNCH1(NC, 0, true) else QMG_MFMA_LAUNCH1(NC, 0, false) }          \
+      else { if (a.mat32) QMG_MFMA_LAUNCH1(NC, 1, true) else QMG_MFMA_LAUNCH1(NC, 1, false) }
       switch (nc) {
         case 8: QMG_MFMA_LAUNCH(8) break;
         case 12: QMG_MFMA_LAUNCH(12) break;
@@ -769,23 +870,28 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
         default: QMG_MFMA_LAUNCH(32) break;
       }
 #undef QMG_MFMA_LAUNCH
+#undef QMG_MFMA_LAUNCH1
     }
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }
 
   if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
-  const GenLayout L = make_gen_layout(nc, a.hr);
+  const GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
   const size_t smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)L.S * nc + (size_t)L.H * L.S * nc);
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
+#define QMG_GEN_CASE1(PT, M32)                                                                          \
+    {                                                                                                   \
+      if (smem > 64 * 1024)                                                                             \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      k_stencil_gen<PT, M32><<<grid, block, smem, st>>>(a, nc, L);                                      \
+    }
 #define QMG_GEN_CASE(PT)                                                                                \
   case PT:                                                                                              \
-    if (smem > 64 * 1024)                                                                               \
-      QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-    k_stencil_gen<PT><<<grid, block, smem, st>>>(a, nc, L);                                            \
+    if (a.mat32) QMG_GEN_CASE1(PT, true) else QMG_GEN_CASE1(PT, false)                                  \
     break;
   switch (L.per_thread) {
     QMG_GEN_CASE(1) QMG_GEN_CASE(2) QMG_GEN_CASE(3) QMG_GEN_CASE(4) QMG_GEN_CASE(5) QMG_GEN_CASE(6)
@@ -793,6 +899,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     default: return QMG_ERR_UNSUPPORTED;
   }
 #undef QMG_GEN_CASE
+#undef QMG_GEN_CASE1
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

@@ -60,6 +60,7 @@ inline int N13::build(int argc, char** argv) {
   }
   cout << setprecision(20);
   if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   x_len = stoi(argv[1]); y_len = stoi(argv[1]);
   mass = stod(argv[2]);
   const double beta = stod(argv[3]);

@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
   }
   cout << setprecision(20);
   if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   const int x_len = stoi(argv[1]), y_len = x_len;
   const double mass = stod(argv[2]);
   const int n_refine = stoi(argv[4]);

@@ -96,6 +96,12 @@ class MultigridMG {
   }
 
  public:
+  // OPT-IN (default off; not in the reference): every Galerkin coarse operator built from now on keeps a complex<float>
+  // copy of its matrices and streams that in ORIGINAL-operator applies (Stencil2D::enable_f32_matrices).  The hierarchy
+  // then only preconditions in reduced storage precision; the outer fp64 flexible solver still converges to its fp64
+  // tolerance.  Drivers switch it on with QMG_COARSE_F32=1.
+  static bool& coarse_f32_storage() { static bool f = false; return f; }
+
   enum QMGMultigridPrecondStencil { QMG_MULTIGRID_PRECOND_ORIGINAL = 0, QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI = 1 };
 
   MultigridMG(Lattice2D* in_lat, Stencil2D* in_stencil) {
@@ -130,6 +136,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list.push_back(new CoarseOperator2D(new_lat, stencil_list[num_levels - 2], lattice_list[num_levels - 2], new_transfer, is_chiral,
                                                   build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra));
+      if (coarse_f32_storage()) stencil_list.back()->enable_f32_matrices();
       is_stencil_managed.push_back(true);
     } else {
       stencil_list.push_back(0);
@@ -175,6 +182,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list[level] = new CoarseOperator2D(new_lat, stencil_list[level - 1], lattice_list[level - 1], new_transfer, is_chiral,
                                                  build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra);
+      if (coarse_f32_storage()) stencil_list[level]->enable_f32_matrices();
       is_stencil_managed[level] = true;
     } else {
       stencil_list[level] = 0;

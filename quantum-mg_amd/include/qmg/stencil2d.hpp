@@ -71,6 +71,11 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (f32_matrices && cl == clover && ho == hopping) {   // opt-in fp32 storage of the ORIGINAL stencil (enable_f32_matrices)
+      d.clover = clover32; d.hopping = hopping32;
+      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat32");
+      return;
+    }
     qmg::ok(qmg_stencil_apply(&d, lhs, rhs, pieces, 1, 0, qmg::current_stream()), "qmg_stencil_apply");
   }
   void launch(unsigned pieces, complex<double>* lhs, complex<double>* rhs) { launch(pieces, lhs, rhs, clover, hopping, shift, eo_shift, dof_shift); }
@@ -83,6 +88,10 @@ struct Stencil2D {
   complex<double>* corner;
   bool generated;
   complex<double> shift, eo_shift, dof_shift;
+  // opt-in: complex<float> copies of clover / hopping that the ORIGINAL-operator applies stream instead of the fp64 arrays
+  bool f32_matrices;
+  void* clover32;
+  void* hopping32;
 
   bool built_dagger;
   complex<double>*dagger_clover, *dagger_hopping, *dagger_twolink, *dagger_corner;
@@ -112,6 +121,7 @@ struct Stencil2D {
     priv_cvector = 0;
     extra_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
     eo_cvector = 0;
+    f32_matrices = false; clover32 = hopping32 = 0;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
     built_rbj_dagger = false; rbj_dagger_clover = rbj_dagger_hopping = rbj_dagger_twolink = rbj_dagger_corner = rbj_dagger_cinv = 0;
@@ -125,7 +135,34 @@ struct Stencil2D {
                                &rbjacobi_clover, &rbjacobi_hopping, &rbjacobi_twolink, &rbjacobi_corner, &rbjacobi_cinv,
                                &rbj_dagger_clover, &rbj_dagger_hopping, &rbj_dagger_twolink, &rbj_dagger_corner, &rbj_dagger_cinv};
     for (auto p : all) if (*p != 0) deallocate_vector(p);
+    disable_f32_matrices();
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
+  }
+
+  // Opt-in storage format for operators that only PRECONDITION (a K-cycle inside a flexible fp64 outer solver): keep a
+  // complex<float> copy of clover and hopping and let every ORIGINAL-operator apply stream that copy -- half the bytes of
+  // an HBM-bound coarse apply.  Vectors, shifts and arithmetic stay fp64; the fp64 arrays remain the master copy (variant
+  // builds read them; a Galerkin build of the next level probes through the applies and so sees the rounded operator).
+  // Call again after changing the matrices.  Not available for nc = 1, 2, 4 (the fine operators).
+  bool enable_f32_matrices() {
+    const int nc = lat->get_nc();
+    if (nc == 1 || nc == 2 || nc == 4) { std::cout << "[QMG-WARNING]: fp32 matrix storage is not available for nc = " << nc << ".\n"; return false; }
+    disable_f32_matrices();
+    if (clover != 0) {
+      if (qmg_malloc(&clover32, (size_t)lat->get_size_cm_l() * 8) != QMG_SUCCESS) { clover32 = 0; return false; }
+      qmg::ok(qmg_c64_to_c32(clover32, clover, (size_t)lat->get_size_cm_l(), qmg::current_stream()), "qmg_c64_to_c32");
+    }
+    if (hopping != 0) {
+      if (qmg_malloc(&hopping32, (size_t)lat->get_size_hopping_l() * 8) != QMG_SUCCESS) { disable_f32_matrices(); return false; }
+      qmg::ok(qmg_c64_to_c32(hopping32, hopping, (size_t)lat->get_size_hopping_l(), qmg::current_stream()), "qmg_c64_to_c32");
+    }
+    f32_matrices = true;
+    return true;
+  }
+  void disable_f32_matrices() {
+    if (clover32) { qmg_free(clover32); clover32 = 0; }
+    if (hopping32) { qmg_free(hopping32); hopping32 = 0; }
+    f32_matrices = false;
   }
 
   void clear_stencils() {   // stencil_2d.h:339-375
@@ -247,6 +284,11 @@ struct Stencil2D {
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
   void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {
     qmg_stencil_desc d = desc();
+    if (f32_matrices) {
+      d.clover = clover32; d.hopping = hopping32;
+      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, QMG_P_ALL | QMG_P_ZERO, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
+      return;
+    }
     qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, QMG_P_ALL | QMG_P_ZERO, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
   }
 

@@ -173,3 +173,37 @@ def test_transfer_batch_matches_single(fd, cd, nrhs, mask):
     for k in range(nrhs):
         if not (mask >> k) & 1:
             assert np.array_equal(got[k * cstride:(k + 1) * cstride], coarse0[k * cstride:(k + 1) * cstride])
+
+
+@pytest.mark.parametrize("nc,nrhs,mask", [(8, 1, 0b1), (24, 1, 0b1), (3, 1, 0b1), (8, 6, 0b101101), (24, 16, 0xFFFF), (12, 3, 0b111), (32, 2, 0b10), (6, 4, 0b1111)])
+def test_stencil_apply_with_f32_stored_matrices(nc, nrhs, mask):
+    """qmg_stencil_apply_mat32 (opt-in storage format): the matrices are read as complex<float>, everything else is fp64.
+    Parity is exact in the sense that matters: equal (1e-13) to the ORACLE's fp64 apply of the matrices rounded to
+    float -- kernels B (one rhs, or nc outside the MFMA set) and C (several rhs, f64 MFMA)."""
+    Lx, Ly = 12, 6
+    vol = Lx * Ly
+    size = vol * nc
+    stride = size + 2
+    clover = cs.gaussian_cvec(vol * nc * nc, 1)
+    hopping = cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    rhs = cs.gaussian_cvec(stride * nrhs, 3)
+    lhs0 = cs.gaussian_cvec(stride * nrhs, 4)
+    shifts = (0.3 - 0.2j, 0.11, -0.07 + 0.02j)
+    dc, dh = D(clover), D(hopping)
+    dc32, dh32 = qmg.DeviceArray(vol * nc * nc // 2 + 1), qmg.DeviceArray(4 * vol * nc * nc // 2 + 1)   # 8 bytes per element
+    qmg.c64_to_c32(dc32, dc, vol * nc * nc)
+    qmg.c64_to_c32(dh32, dh, 4 * vol * nc * nc)
+    r32 = lambda a: a.astype(np.complex64).astype(np.complex128)
+    od = ol.make_desc(Lx, Ly, nc, r32(clover), r32(hopping), *shifts)
+    gd = qmg.make_desc(Lx, Ly, nc, dc32, dh32, *shifts)
+    for pieces in (ol.P_ALL | ol.P_ZERO, ol.P_ALL, ol.P_EO | ol.P_ZERO_E, ol.P_CLOVER | ol.P_SHIFT):
+        want = lhs0.copy()
+        for k in active(mask, nrhs):
+            ol.stencil_apply(od, np.ascontiguousarray(rhs[k * stride:k * stride + size]), pieces, lhs=want[k * stride:k * stride + size])
+        dl = D(lhs0)
+        qmg.stencil_apply_mat32(gd, dl, D(rhs), pieces, nrhs, stride, mask)
+        assert cs.rel_l2(dl.to_host(), want) < TOL, hex(pieces)
+    # nc = 1, 2, 4 are not served
+    import ctypes as C
+    d2 = qmg.make_desc(Lx, Ly, 2, dc32, dh32)
+    assert qmg.lib().qmg_stencil_apply_mat32(C.byref(d2), C.c_void_p(dc.ptr), C.c_void_p(dh.ptr), C.c_uint(0xFFF), 1, C.c_size_t(0), C.c_uint(1), None) == 3

@@ -157,3 +157,19 @@ def test_n22_four_levels_and_batched_setup(golden_dir):
     assert res["batched"][2] and not res["sequential"][2]
     assert res["batched"][1] <= 1.05e-10 and res["sequential"][1] <= 1.05e-10
     assert abs(res["batched"][0] - res["sequential"][0]) <= 1
+
+
+def test_kcycle_with_f32_stored_coarse_operators(golden_dir):
+    """QMG_COARSE_F32=1 (opt-in): the Galerkin operators are streamed as complex<float>; the hierarchy only preconditions,
+    so the outer fp64 VPGCR still reaches 1e-10 in (about) the same number of iterations."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    its = {}
+    for tag, extra in (("f64", {}), ("f32", {"QMG_COARSE_F32": "1"})):
+        out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle_mrhs"), "128", "-0.07", "6.0", "2", "8", gauge_file, "64", "3", "verify"],
+                             cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", **extra), capture_output=True, text=True, timeout=150)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert ("complex<float>" in out.stdout) == (tag == "f32")
+        rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+        assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows)
+        its[tag] = [int(r[1]) for r in rows]
+    assert all(abs(a - b) <= 2 for a, b in zip(its["f64"], its["f32"])), its
