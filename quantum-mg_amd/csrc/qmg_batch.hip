@@ -208,17 +208,33 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong(const cplx* __restrict__ nul
       const int cx = (2 * j + s) / g.bx;
       const long ci = bcoarse_site_index(g, cx, cy);
       const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr) * g.fnc + t;
+      // per-slot base pointers outside the d loop; unused slots alias slot 0 (computed, discarded): no branches inside
       cplx acc[KB];
+      const cplx* cq[KB];
 #pragma unroll
-      for (int q = 0; q < KB; q++) acc[q] = (q < ns) ? fine[(long)bi.id[s0 + q] * fstride + e] : cmake(0.0, 0.0);
-      for (int d = 0; d < nvec; d++) {
-        const cplx* src = nullv + (long)d * g.fsize + e;
-        cplx nv;
-        nv.x = __builtin_nontemporal_load(&src->x);
-        nv.y = __builtin_nontemporal_load(&src->y);
+      for (int q = 0; q < KB; q++) {
+        const long id = bi.id[s0 + ((q < ns) ? q : 0)];
+        cq[q] = coarse + id * cstride + ci * g.cnc;
+        acc[q] = fine[id * fstride + e];
+      }
+      int d = 0;
+      for (; d + 4 <= nvec; d += 4) {   // four null-vector loads in flight
+        cplx nv[4];
 #pragma unroll
-        for (int q = 0; q < KB; q++)
-          if (q < ns) cmac(acc[q], nv, coarse[(long)bi.id[s0 + q] * cstride + ci * g.cnc + d]);
+        for (int u = 0; u < 4; u++) {
+          const cplx* src = nullv + (long)(d + u) * g.fsize + e;
+          nv[u].x = __builtin_nontemporal_load(&src->x);
+          nv[u].y = __builtin_nontemporal_load(&src->y);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < KB; q++) cmac(acc[q], nv[u], cq[q][d + u]);
+      }
+      for (; d < nvec; d++) {
+        const cplx nv = nullv[(long)d * g.fsize + e];
+#pragma unroll
+        for (int q = 0; q < KB; q++) cmac(acc[q], nv, cq[q][d]);
       }
 #pragma unroll
       for (int q = 0; q < KB; q++)
@@ -248,6 +264,9 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict(const cplx* __restrict__ nu
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int wpg = (TG > WAVE) ? TG / WAVE : 1;   // wavefronts per group
   const long ngroups = (ncs + NS - 1) / NS;
+  const cplx* fq[KB];
+#pragma unroll
+  for (int k = 0; k < KB; k++) fq[k] = fine + (long)bi.id[s0 + ((k < ns) ? k : 0)] * fstride;
   for (long wg = blockIdx.x; wg < ngroups; wg += gridDim.x) {
     const long cs = wg * NS + grp;
     const bool live = cs < ncs;
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict(const cplx* __restrict__ nu
           const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc + el;
           cplx f[KB];
 #pragma unroll
-          for (int k = 0; k < KB; k++) f[k] = (k < ns) ? fine[(long)bi.id[s0 + k] * fstride + e] : cmake(0.0, 0.0);
+          for (int k = 0; k < KB; k++) f[k] = fq[k][e];   // (unused slots alias slot 0: computed, discarded)
 #pragma unroll
           for (int q = 0; q < BX_DC; q++)
             if (q < dn) {
