@@ -16,6 +16,7 @@
 #include <string>
 
 #include "../include/qmg/qmg.hpp"
+#include "mrhs_solve.hpp"
 
 using namespace std;
 
@@ -144,7 +145,13 @@ int main(int argc, char** argv) {
   cout << setprecision(6) << "[QMG-TIMING]: solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
   mg_object->check_in(b_prep, 0); mg_object->check_in(x_reconstruct, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
 
-  const bool ok_ = invif.success && true_res < 20 * tol;
+  bool ok_ = invif.success && true_res < 20 * tol;
+  // "nrhs=K" as the last argument (not in n19): K more gaussian systems, solved as Schur systems in one lock-step batch
+  int nrhs_batched = 0;
+  for (int i = 1; i < argc; i++) if (string(argv[i]).rfind("nrhs=", 0) == 0) nrhs_batched = stoi(string(argv[i]).substr(5));
+  if (nrhs_batched > 0)
+    ok_ = mrhs_solve_and_report(mg_object, lats[0], nrhs_batched, seed, tol, max_iter, restart_freq, getenv("QMG_QUIET") != 0, getenv("QMG_MRHS_VERIFY") ? 1 : 0, 0.0, 0, 0,
+                                solve_type) && ok_;
   delete mg_object;
   for (int i = 0; i < n_refine; i++) { delete transfer_objs[i]; delete level_solve_objs[i]; }
   delete[] transfer_objs; delete[] level_solve_objs; delete coarsest_solve_obj;

@@ -13,9 +13,10 @@
 // bit-identical to the single-vector ones, the MFMA apply and the blocked transfer differ in summation order only
 // (1e-13), so a batched solve reproduces the single solves to solver tolerance with the same iteration counts (+-1).
 //
-// Scope (this round): the ORIGINAL operator on every level with MR smoothers and GCR coarse solves, i.e. the n13
-// configuration (stateful_multigrid.h:734-1060 with fine_stencil_app = coarsest_stencil_app = QMG_MATVEC_ORIGINAL, no
-// CGNE/CGNR smoothers).  Other configurations are rejected loudly, not emulated.
+// Scope (this round): MR smoothers and GCR coarse solves with the ORIGINAL operator (n13, n22) or the right-block-Jacobi
+// Schur complement (n19) on every level (stateful_multigrid.h:734-1060 with fine_stencil_app / coarsest_stencil_app in
+// {QMG_MATVEC_ORIGINAL, QMG_MATVEC_RIGHT_SCHUR}, no CGNE/CGNR smoothers).  Other configurations are rejected loudly
+// (BatchKcycle::supported), not emulated.
 #ifndef QMG_BATCH_HPP
 #define QMG_BATCH_HPP
 
@@ -151,6 +152,53 @@ inline void apply_stencil_2D_M_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned ma
   ((Stencil2D*)extra_data)->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
 }
 
+// ---- operator variants for a batch: ORIGINAL and the right-block-Jacobi Schur complement (stencil_2d.h:1886-1983) ----
+struct BatchOp {
+  Stencil2D* st;
+  QMGStencilType type;
+  BatchOp(Stencil2D* st_, QMGStencilType type_) : st(st_), type(type_) {}
+  static bool supported(QMGStencilType t) { return t == QMG_MATVEC_ORIGINAL || t == QMG_MATVEC_RIGHT_SCHUR; }
+};
+inline qmg::Batch batch_odd_half(qmg::Batch v, size_t half) { return qmg::Batch(v.p + half, v.stride, v.nrhs); }
+
+// lhs_e = rhs_e - D'_eo D'_oe rhs_e (apply_M_rbjacobi_schur, :1886-1908); only the even halves are read / written
+inline void apply_M_rbjacobi_schur_batch(Stencil2D* st, qmg::Batch lhs, qmg::Batch rhs, unsigned mask) {
+  if (!st->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_schur, but the rbjacobi stencil has not been allocated.\n"; return; }
+  const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
+  qmg::BatchPool pool(lhs.stride, lhs.nrhs);
+  qmg::Batch t = pool.get();
+  const complex<double>* rh = st->rbjacobi_hopping_in_use();
+  st->launch_batch(QMG_P_OE | QMG_P_ZERO_O, t.p, rhs.p, 0, rh, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  st->launch_batch(QMG_P_EO | QMG_P_ZERO_E, t.p, t.p, 0, rh, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  qmg::bxmyz(rhs, t, lhs, half, mask);
+}
+inline void apply_stencil_typed_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data) {
+  BatchOp* op = (BatchOp*)extra_data;
+  if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch(op->st, lhs, rhs, mask);
+  else op->st->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
+}
+// b_prep = prepare_M(b) (stencil_2d.h:2455-2490), b_prep OVERWRITTEN over the full vector
+inline void prepare_M_batch(Stencil2D* st, QMGStencilType type, qmg::Batch b_prep, qmg::Batch b, unsigned mask) {
+  const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
+  if (type == QMG_MATVEC_RIGHT_SCHUR) {   // b_e - D'_eo b_o on the even half, zero on the odd half (:1912-1928)
+    st->launch_batch(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, 0, st->rbjacobi_hopping_in_use(), 0.0, 0.0, 0.0, b.nrhs, b.stride, mask);
+    qmg::bxmyz(b, b_prep, b_prep, half, mask);
+    qmg::bzero(batch_odd_half(b_prep, half), cv - half, mask);
+  } else qmg::bcopy(b_prep, b, cv, mask);
+}
+// x = reconstruct_M(y, b) (:2492-2527), x OVERWRITTEN
+inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::Batch x, qmg::Batch y, qmg::Batch b, unsigned mask) {
+  const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
+  if (type == QMG_MATVEC_RIGHT_SCHUR) {   // (:1932-1957) t_o = b_o - D'_oe y_e ; t_e = y_e ; x = C^-1 t
+    qmg::BatchPool pool(x.stride, x.nrhs);
+    qmg::Batch t = pool.get();
+    st->launch_batch(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, 0, st->rbjacobi_hopping_in_use(), 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+    qmg::bxmyz(batch_odd_half(b, half), batch_odd_half(t, half), batch_odd_half(t, half), cv - half, mask);
+    qmg::bcopy(t, y, half, mask);
+    st->launch_batch(QMG_P_CLOVER | QMG_P_ZERO, x.p, t.p, st->rbjacobi_cinv, 0, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+  } else qmg::bcopy(x, y, cv, mask);
+}
+
 // ---------------------------------------------------------------------------------------------
 // MR(omega) for a batch: minv_vector_minres of krylov.hpp per system, in lock step.  x0 = 0 is REQUIRED (every use in the
 // K-cycle; the caller has zeroed phi): r0 = b.
@@ -215,9 +263,12 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi
 // ---------------------------------------------------------------------------------------------
 inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, int size, int max_iter, double eps, int restart_freq,
                                              batch_matrix_op matrix_vector, void* extra_info, batch_precond_op precond, void* precond_info,
-                                             unsigned mask, bool zero_guess, inversion_verbose_struct* verb, const char* name) {
+                                             unsigned mask, bool zero_guess, inversion_verbose_struct* verb, const char* name,
+                                             const std::vector<double>* eps_per_system = 0) {
   const int nrhs = phi.nrhs;
   std::vector<inversion_info> inv(nrhs);
+  std::vector<double> epsv(nrhs, eps);   // relative tolerance per system (the K-cycle's inner tolerance depends on the system)
+  if (eps_per_system) epsv = *eps_per_system;
   const int basis_max = (restart_freq > 0) ? restart_freq : max_iter;
   qmg::BatchPool pool(phi.stride, nrhs);
   qmg::Batch r = pool.get(), tmp = pool.get();
@@ -256,7 +307,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
     bnorm[k] = std::sqrt(bsq[k]);
     rsq_ref[k] = rsq[k];
     if (!qmg::is_active(mask, k)) continue;
-    conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < eps * bnorm[k]);
+    conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < epsv[k] * bnorm[k]);
     if (!conv[k] && max_iter > 0) act |= 1u << k;
   }
   int kb = 0;
@@ -298,7 +349,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
       used[k] = kb + 1;
       upd |= 1u << k;
       rsq[k] = rsq[k] - std::norm(wr) / ww;
-      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * eps * bnorm[k]) renorm |= 1u << k;
+      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * epsv[k] * bnorm[k]) renorm |= 1u << k;
     }
     qmg::bcaxpy(malpha, w, r, size, upd);
     if (renorm) {
@@ -310,7 +361,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
       if (!qmg::is_active(upd, k)) continue;
       its[k]++;
       if (verb && verb->verbosity == VERB_DETAIL) std::cout << verb->verb_prefix << name << " rhs " << k << " Iter " << its[k] << " RelTol " << std::sqrt(rsq[k]) / bnorm[k] << "\n";
-      if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+      if (std::sqrt(rsq[k]) < epsv[k] * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
     }
     if (kb == basis_max) flush_x();   // the basis is about to be reused: bring every pending x up to date (frozen systems too)
     if (act && kb == basis_max) {   // restart: true residual, drop the basis (before the iteration cap, as in krylov.hpp)
@@ -322,7 +373,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
         if (!qmg::is_active(act, k)) continue;
         ops[k]++;
         rsq[k] = t[k]; rsq_ref[k] = t[k];
-        if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+        if (std::sqrt(rsq[k]) < epsv[k] * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
       }
     }
     for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k) && its[k] >= max_iter) act &= ~(1u << k);
@@ -344,14 +395,15 @@ struct BatchKcycle {
   StatefulMultigridMG* mg;
   int nrhs;
   BatchKcycle(StatefulMultigridMG* mg_, int nrhs_) : mg(mg_), nrhs(nrhs_) {}
-  // the configuration the batched cycle implements
+  // the configurations the batched cycle implements: ORIGINAL or RIGHT_SCHUR on every level, MR smoothers, GCR coarse solves
   bool supported() {
     const int nl = mg->get_num_levels();
+    if (nl < 2) return false;
     for (int i = 0; i < nl - 1; i++) {
       StatefulMultigridMG::LevelSolveMG* ls = mg->get_level_solve(i);
-      if (!ls || ls->fine_stencil_app != QMG_MATVEC_ORIGINAL || ls->pre_cgne || ls->post_cgne) return false;
+      if (!ls || !BatchOp::supported(ls->fine_stencil_app) || ls->pre_cgne || ls->post_cgne) return false;
     }
-    return mg->get_coarsest_solve()->coarsest_stencil_app == QMG_MATVEC_ORIGINAL && nl >= 2;
+    return BatchOp::supported(mg->get_coarsest_solve()->coarsest_stencil_app);
   }
 };
 
@@ -375,15 +427,22 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   for (int i = 1; i < level + 1; i++) verb2.verb_prefix += "  ";
   verb2.verb_prefix += "[QMG-MG-SOLVE-INFO]: Level " + std::to_string(level + 1) + " ";
 
+  const QMGStencilType fine_type = level_solve->fine_stencil_app;
+  BatchOp fine_op(fine_stencil, fine_type);
+  const size_t fine_size_solve = (fine_type == QMG_MATVEC_RIGHT_SCHUR) ? fine_size / 2 : fine_size;
+
   int coarse_max_iter, coarse_restart;
   double coarse_tol;
+  QMGStencilType coarse_type;
   if (level < total_num_levels - 2) {
     StatefulMultigridMG::LevelSolveMG* cs = mg->get_level_solve(level + 1);
-    coarse_max_iter = cs->intermediate_iters; coarse_tol = cs->intermediate_tol; coarse_restart = cs->intermediate_restart_freq;
+    coarse_type = cs->fine_stencil_app; coarse_max_iter = cs->intermediate_iters; coarse_tol = cs->intermediate_tol; coarse_restart = cs->intermediate_restart_freq;
   } else {
     StatefulMultigridMG::CoarsestSolveMG* cs = mg->get_coarsest_solve();
-    coarse_max_iter = cs->coarsest_iters; coarse_tol = cs->coarsest_tol; coarse_restart = cs->coarsest_restart_freq;
+    coarse_type = cs->coarsest_stencil_app; coarse_max_iter = cs->coarsest_iters; coarse_tol = cs->coarsest_tol; coarse_restart = cs->coarsest_restart_freq;
   }
+  BatchOp coarse_op(coarse_stencil, coarse_type);
+  const size_t coarse_size_solve = (coarse_type == QMG_MATVEC_RIGHT_SCHUR) ? coarse_size / 2 : coarse_size;
 
   // scratch for this level (recycled through VecPool's per-length free lists)
   qmg::BatchPool fpool(fine_size, nrhs), cpool(coarse_size, nrhs);
@@ -397,52 +456,64 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   // ---- 1. pre-smooth: A z1 ~ rhs, r1 = rhs - A z1
   qmg::bzero(z1, fine_size, mask);
   if (level_solve->pre_iters > 0) {
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z1, rhs, (int)fine_size, level_solve->pre_iters, level_solve->pre_tol, 0.85,
-                                                                      apply_stencil_2D_M_batch, (void*)fine_stencil, mask);
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z1, rhs, (int)fine_size_solve, level_solve->pre_iters, level_solve->pre_tol, 0.85,
+                                                                      apply_stencil_typed_batch, (void*)&fine_op, mask);
     count(QMG_DSLASH_TYPE_PRESMOOTH, inv, level);
-    apply_stencil_2D_M_batch(Atmp, z1, mask, (void*)fine_stencil);
+    apply_stencil_typed_batch(Atmp, z1, mask, (void*)&fine_op);
     mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
-    qmg::bxmyz(rhs, Atmp, r1, fine_size, mask);
+    qmg::bxmyz(rhs, Atmp, r1, fine_size_solve, mask);
   } else {
-    qmg::bcopy(r1, rhs, fine_size, mask);
-    qmg::bcopy(z1, rhs, fine_size, mask);
+    qmg::bcopy(r1, rhs, fine_size_solve, mask);
+    qmg::bcopy(z1, rhs, fine_size_solve, mask);
   }
+  // (Schur: the odd half of r1 must not leak stale pool data into the restriction)
+  if (fine_type == QMG_MATVEC_RIGHT_SCHUR) qmg::bzero(batch_odd_half(r1, fine_size_solve), fine_size - fine_size_solve, mask);
 
-  // ---- 2. restrict, coarse solve (recursion = the "K"), prolong
-  qmg::Batch r_coarse = cpool.get(), e_coarse = cpool.get();
+  // ---- 2. restrict, prepare, coarse solve (recursion = the "K"), reconstruct
+  qmg::Batch r_coarse = cpool.get(), r_coarse_prep = cpool.get(), e_coarse = cpool.get(), e_rec = cpool.get();
   qmg::bzero(r_coarse, coarse_size, mask);
   transfer->restrict_f2c_batch(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
-  // (ORIGINAL operator: prepare_M is a copy, so rnorm_prep == rnorm and the inner tolerance is coarse_tol, multigrid.hpp)
+  std::vector<double> inner_tol(nrhs, coarse_tol);
+  if (coarse_type == QMG_MATVEC_ORIGINAL) qmg::bcopy(r_coarse_prep, r_coarse, coarse_size, mask);   // prepare_M is a copy; rnorm_prep == rnorm
+  else {
+    const std::vector<double> rn = qmg::bnorm2sq(r_coarse, coarse_size, mask);
+    prepare_M_batch(coarse_stencil, coarse_type, r_coarse_prep, r_coarse, mask);
+    const std::vector<double> rp = qmg::bnorm2sq(r_coarse_prep, coarse_size, mask);
+    for (int k = 0; k < nrhs; k++)
+      if (qmg::is_active(mask, k) && rp[k] > 0.0) inner_tol[k] = coarse_tol * std::sqrt(rn[k]) / std::sqrt(rp[k]);
+  }
   qmg::bzero(e_coarse, coarse_size, mask);
   std::vector<inversion_info> cinv;
   if (level == total_num_levels - 2) {
-    cinv = bgcr_core(e_coarse, r_coarse, (int)coarse_size, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_2D_M_batch, (void*)coarse_stencil, 0, 0,
-                     mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart");
+    cinv = bgcr_core(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch, (void*)&coarse_op, 0, 0,
+                     mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart", &inner_tol);
   } else {
     mg->go_coarser();
-    cinv = bgcr_core(e_coarse, r_coarse, (int)coarse_size, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_2D_M_batch, (void*)coarse_stencil,
-                     mg_preconditioner_batch, (void*)bk, mask, true, &verb2, coarse_restart == -1 ? "VPGCR" : "VPGCR-restart");
+    cinv = bgcr_core(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch, (void*)&coarse_op,
+                     mg_preconditioner_batch, (void*)bk, mask, true, &verb2, coarse_restart == -1 ? "VPGCR" : "VPGCR-restart", &inner_tol);
     mg->go_finer();
   }
   for (int k = 0; k < nrhs; k++)
     if (qmg::is_active(mask, k)) { mg->add_tracker_count(QMG_DSLASH_TYPE_KRYLOV, cinv[k].ops_count, level + 1); mg->add_iterations_count(cinv[k].iter, level + 1); }
+  reconstruct_M_batch(coarse_stencil, coarse_type, e_rec, e_coarse, r_coarse, mask);
 
   // ---- 3. prolong and correct: lhs = z1 + P e
   qmg::Batch z2 = r1;   // r1 is free again
   qmg::bzero(z2, fine_size, mask);
-  transfer->prolong_c2f_batch(e_coarse.p, e_coarse.stride, z2.p, z2.stride, nrhs, mask);
-  qmg::bcxpyz(z1, z2, lhs, fine_size, mask);
+  transfer->prolong_c2f_batch(e_rec.p, e_rec.stride, z2.p, z2.stride, nrhs, mask);
+  if (coarse_type == QMG_MATVEC_RIGHT_SCHUR) qmg::bzero(batch_odd_half(z2, fine_size / 2), fine_size - fine_size / 2, mask);   // as multigrid.hpp
+  qmg::bcxpyz(z1, z2, lhs, fine_size_solve, mask);
 
   // ---- 4. post-smooth on r2 = rhs - A lhs
   if (level_solve->post_iters > 0) {
-    apply_stencil_2D_M_batch(Atmp, lhs, mask, (void*)fine_stencil);
+    apply_stencil_typed_batch(Atmp, lhs, mask, (void*)&fine_op);
     qmg::Batch r2 = z2, z3 = z1;   // both free again
-    qmg::bxmyz(rhs, Atmp, r2, fine_size, mask);
+    qmg::bxmyz(rhs, Atmp, r2, fine_size_solve, mask);
     qmg::bzero(z3, fine_size, mask);
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z3, r2, (int)fine_size, level_solve->post_iters, level_solve->post_tol, 0.85,
-                                                                      apply_stencil_2D_M_batch, (void*)fine_stencil, mask);
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
+                                                                      apply_stencil_typed_batch, (void*)&fine_op, mask);
     count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
-    qmg::bcxpy(z3, lhs, fine_size, mask);
+    qmg::bcxpy(z3, lhs, fine_size_solve, mask);
   }
 }
 

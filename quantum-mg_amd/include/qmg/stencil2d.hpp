@@ -280,6 +280,19 @@ struct Stencil2D {
   }
   // lhs = A rhs without a separate zeroing pass (what the C wrappers do, :2571-2576)
   void apply_M_overwrite(complex<double>* lhs, complex<double>* rhs) { launch(QMG_P_ALL | QMG_P_ZERO, lhs, rhs); }
+  // The one launch of the batch layer (include/qmg/batch.hpp): `launch` for <= 16 vectors `stride` apart, active systems only.
+  void launch_batch(unsigned pieces, complex<double>* lhs, complex<double>* rhs, const complex<double>* cl, const complex<double>* ho,
+                    complex<double> s, complex<double> es, complex<double> ds, int nrhs, size_t stride, unsigned mask) {
+    qmg_stencil_desc d;
+    d.Lx = lat->get_dim_mu(0); d.Ly = lat->get_dim_mu(1); d.nc = lat->get_nc();
+    d.clover = cl; d.hopping = ho;
+    d.shift[0] = s.real(); d.shift[1] = s.imag();
+    d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
+    d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
+  }
+  const complex<double>* rbjacobi_hopping_in_use() const { return swap_rbjacobi ? hopping : rbjacobi_hopping; }
+
   // lhs_k = M rhs_k for the active systems of a lock-step batch (<= 16 vectors `stride` apart): one read of the matrices;
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
   void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {

@@ -173,3 +173,20 @@ def test_kcycle_with_f32_stored_coarse_operators(golden_dir):
         assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows)
         its[tag] = [int(r[1]) for r in rows]
     assert all(abs(a - b) <= 2 for a, b in zip(its["f64"], its["f32"])), its
+
+
+def test_batched_schur_kcycle_reproduces_the_single_solves(golden_dir):
+    """n19 configuration (even-odd Schur complement of the right-block-Jacobi operator on every level, four levels
+    128 -> 32 -> 8 -> 2) for a lock-step batch: prepare / Schur solve / reconstruct per system, inner tolerances per
+    system (coarse_tol |r| / |r_prep|), verified against the single-vector path system by system."""
+    gauge_file = os.path.join(golden_dir, "l128t128b60_heatbath.dat")
+    out = subprocess.run([os.path.join(DRIVERS, "n19_wilson_kcycle_precond"), "128", "3", gauge_file, "128", "nrhs=3"], cwd=DRIVERS,
+                         env=dict(os.environ, QMG_QUIET="1", QMG_MRHS_VERIFY="1"), capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+    rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+    assert len(rows) == 3 and all(float(r[3]) <= 2e-8 for r in rows)     # n19 solves to 1e-8
+    ver = re.findall(r"\[QMG-MRHS-VERIFY\]: rhs (\d+) single-path iterations (\d+) \(batched (\d+)\) ; relative solution difference ([-\d.e+]+)", out.stdout)
+    assert len(ver) == 3
+    for _, single_it, batch_it, diff in ver:
+        assert abs(int(single_it) - int(batch_it)) <= 1 and float(diff) < 1e-6
