@@ -401,14 +401,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 #pragma unroll
           for (int q = 0; q < PTS / 2; q++) {
             const int el = 2 * (tid + q * BLOCK);
-            if (el < lim) ldm32_pair<false>(mbase, moff + el, stage[2 * q], stage[2 * q + 1]);
+            if (el < lim) ldm32_pair<true>(mbase, moff + el, stage[2 * q], stage[2 * q + 1]);
             else { stage[2 * q] = cmake(0.0, 0.0); stage[2 * q + 1] = cmake(0.0, 0.0); }
           }
         } else {
 #pragma unroll
           for (int q = 0; q < PT; q++) {
             const int el = tid + q * BLOCK;
-            stage[q] = (el < lim) ? ldm<M32, false>(mbase, moff + el) : cmake(0.0, 0.0);
+            stage[q] = (el < lim) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
           }
         }
         // neighbour vector element for (site, c) = tid / nc, tid % nc
