@@ -332,12 +332,15 @@ struct GenLayout {
 
 constexpr int GEN_MAX_PER_THREAD = 12;   // register-staged matrix elements per thread per piece
 
-template <int PT, bool M32>
+// KR = right-hand sides per pass: the matrix tile parked in LDS is used for KR vectors (KR accumulators per thread), so a
+// batch reads the matrices once per KR systems for ANY nc -- the vector-FMA counterpart of kernel C, and the better one
+// where the 16x16 MFMA tile would be mostly padding (nc = 8: 1024^2, 8 rhs 2.0 ms on the matrix cores).
+template <int PT, bool M32, int KR>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* mlds = reinterpret_cast<cplx*>(smem_raw);                    // [S*nc rows][rs]
-  cplx* xlds = mlds + (size_t)L.S * nc * L.rs;                        // [S][nc]
-  cplx* red = xlds + (size_t)L.S * nc;                                // [H][S*nc]
+  cplx* xlds = mlds + (size_t)L.S * nc * L.rs;                        // [KR][S][nc]
+  cplx* red = xlds + (size_t)KR * L.S * nc;                           // [H][S*nc]
 
   const int tid = threadIdx.x;
   const int rows = L.S * nc;             // (s, r) pairs in this block
@@ -369,10 +372,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
     const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
     const int ym = (y == 0) ? a.Ly - 1 : y - 1;
 
-    for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + rhs_offset(a, k);
-      cplx* out = a.lhs + rhs_offset(a, k);
-      cplx acc = cmake(0.0, 0.0);
+    for (int k0 = 0; k0 < a.nrhs; k0 += KR) {
+      const int nk = (a.nrhs - k0 < KR) ? a.nrhs - k0 : KR;
+      cplx acc[KR];
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) acc[kk] = cmake(0.0, 0.0);
 
       // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
       const int order[5] = {4, 0, 1, 2, 3};
@@ -381,7 +385,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
       constexpr int PTS = PT + (PT & 1);
       const bool pairs = M32 && !(nc & 1);
       cplx stage[PTS];
-      cplx xstage = cmake(0.0, 0.0);
+      cplx xstage[KR];
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) xstage[kk] = cmake(0.0, 0.0);
       int cur = -1;
       // find first active piece and prefetch it
       int oi = 0;
@@ -421,7 +427,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
           else if (piece == 1) nbsite = opp + (long)yp * a.hr + j;
           else if (piece == 2) { int jm = j + s - 1; if (jm < 0) jm = a.hr - 1; nbsite = opp + (long)y * a.hr + jm; }
           else nbsite = opp + (long)ym * a.hr + j;
-          xstage = x[nbsite * nc + cc];
+#pragma unroll
+          for (int kk = 0; kk < KR; kk++)
+            if (kk < nk) xstage[kk] = a.rhs[rhs_offset(a, k0 + kk) + nbsite * nc + cc];
         }
       };
       if (oi < 5) { cur = order[oi]; prefetch(cur); }
@@ -449,7 +457,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
             }
           }
         }
-        if (tid < L.S * nc) xlds[tid] = xstage;
+        if (tid < L.S * nc) {
+#pragma unroll
+          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[kk];
+        }
         // issue the next piece's global loads before computing on this one
         int nxt = -1;
         oi++;
@@ -459,9 +470,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
         if (worker && s_of < nsite && !(a.ablate & 32)) {
           const cplx* mrow = mlds + (size_t)sr * L.rs;
           const cplx* xs = xlds + s_of * nc;
-          for (int cc = c0; cc < c1; cc++) cmac(acc, mrow[cc], xs[cc]);
+          for (int cc = c0; cc < c1; cc++) {
+            const cplx m = mrow[cc];          // one LDS read of the matrix element serves all KR right-hand sides
+#pragma unroll
+            for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
+          }
         }
-        if (a.ablate & 32) acc = cadd(acc, stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
+        if (a.ablate & 32) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
         cur = nxt;
       }
 
@@ -471,18 +486,25 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
         const double dg = (nc % 2 == 0) ? ((r_of < nc / 2) ? 1.0 : -1.0) : 0.0;
         const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
                               a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
-        cmac(acc, sh, x[(site0 + s_of) * nc + r_of]);
+#pragma unroll
+        for (int kk = 0; kk < KR; kk++)
+          if (kk < nk) cmac(acc[kk], sh, a.rhs[rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of]);
       }
-      // sum the H slices
-      __syncthreads();
-      if (worker) red[(size_t)h * rows + sr] = acc;
-      __syncthreads();
-      if (h == 0 && s_of < nsite) {
-        cplx t = red[sr];
-        for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
-        const long o = (site0 + s_of) * nc + r_of;
-        if (!do_zero) t = cadd(out[o], t);
-        out[o] = t;
+      // sum the H slices, one right-hand side at a time through the same LDS buffer
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) {
+        if (kk >= nk) break;
+        __syncthreads();
+        if (worker) red[(size_t)h * rows + sr] = acc[kk];
+        __syncthreads();
+        if (h == 0 && s_of < nsite) {
+          cplx t = red[sr];
+          for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
+          cplx* out = a.lhs + rhs_offset(a, k0 + kk);
+          const long o = (site0 + s_of) * nc + r_of;
+          if (!do_zero) t = cadd(out[o], t);
+          out[o] = t;
+        }
       }
     }
   }
@@ -842,7 +864,10 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     return QMG_SUCCESS;
   }
 
-  if (a.nrhs > 1 && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
+  // several right-hand sides against one matrix read: kernel C (f64 MFMA) from 4 systems up -- measured 512^2 nc = 24, 8 rhs:
+  // 2.84 ms against 4.84 ms for the vector-FMA kernel B, which tops out near 10 TFLOP/s on LDS traffic; with 2-3 systems
+  // kernel B's shared tile wins (nc = 8, 1024^2, 3 rhs: 1.06 vs 1.39 ms) and it serves every other nc
+  if (a.nrhs >= 4 && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
     // kernel C: up to 16 right-hand sides per pass share one read of the matrices
     const unsigned gx = (unsigned)((a.hr + BLOCK / WAVE - 1) / (BLOCK / WAVE));
     dim3 grid(gx, gy), block(BLOCK);
@@ -879,16 +904,24 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
   const GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
-  const size_t smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)L.S * nc + (size_t)L.H * L.S * nc);
+  // right-hand sides per pass of kernel B: as many as there are, up to 8 (accumulators) and what LDS holds
+  int kr = (a.nrhs >= 5) ? 8 : (a.nrhs >= 2) ? 4 : 1;
+  size_t smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)kr * L.S * nc + (size_t)L.H * L.S * nc);
+  while (kr > 1 && smem > 64 * 1024) {   // keep >= 2 blocks per CU
+    kr = (kr == 8) ? 4 : 1;
+    smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)kr * L.S * nc + (size_t)L.H * L.S * nc);
+  }
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
-#define QMG_GEN_CASE1(PT, M32)                                                                          \
+#define QMG_GEN_CASE2(PT, M32, KR)                                                                      \
     {                                                                                                   \
       if (smem > 64 * 1024)                                                                             \
-        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-      k_stencil_gen<PT, M32><<<grid, block, smem, st>>>(a, nc, L);                                      \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32, KR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      k_stencil_gen<PT, M32, KR><<<grid, block, smem, st>>>(a, nc, L);                                  \
     }
+#define QMG_GEN_CASE1(PT, M32)                                                                          \
+    { if (kr == 8) QMG_GEN_CASE2(PT, M32, 8) else if (kr == 4) QMG_GEN_CASE2(PT, M32, 4) else QMG_GEN_CASE2(PT, M32, 1) }
 #define QMG_GEN_CASE(PT)                                                                                \
   case PT:                                                                                              \
     if (a.mat32) QMG_GEN_CASE1(PT, true) else QMG_GEN_CASE1(PT, false)                                  \
@@ -900,6 +933,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   }
 #undef QMG_GEN_CASE
 #undef QMG_GEN_CASE1
+#undef QMG_GEN_CASE2
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
