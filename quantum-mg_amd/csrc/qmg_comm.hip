@@ -7,6 +7,7 @@
 // librccl is loaded lazily with dlopen so that single-GPU users (and the CPU build check) do not need
 // it; the calls return QMG_ERR_UNSUPPORTED if it cannot be loaded.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "qmg_common.h"
@@ -35,6 +36,7 @@ struct Rccl {
   fn_get_error_string get_error_string = nullptr;
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  bool force = false;
   bool load() {
     if (handle) return true;
     handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -71,7 +73,8 @@ int qmg_comm_init(const void* id128, int world, int rank) {
   if (!id128 || world < 1 || rank < 0 || rank >= world) return QMG_ERR_INVALID;
   g_rccl.world = world;
   g_rccl.rank = rank;
-  if (world == 1) return QMG_SUCCESS;
+  g_rccl.force = getenv("QMG_COMM_FORCE_RCCL") != nullptr;   // test hook: a 1-rank communicator still goes through RCCL
+  if (world == 1 && !g_rccl.force) return QMG_SUCCESS;
   if (!g_rccl.load()) return QMG_ERR_UNSUPPORTED;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
@@ -88,7 +91,7 @@ int qmg_comm_world(int* world, int* rank) {
 // In-place sum over ranks of n doubles in HBM, asynchronous on `stream`. world == 1: no-op.
 int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream) {
   if (!buf_dev && n) return QMG_ERR_INVALID;
-  if (g_rccl.world == 1 || n == 0) return QMG_SUCCESS;
+  if ((g_rccl.world == 1 && !g_rccl.force) || n == 0) return QMG_SUCCESS;
   if (!g_rccl.comm) return QMG_ERR_INVALID;
   if (g_rccl.all_reduce(buf_dev, buf_dev, n, ncclFloat64V, ncclSumV, g_rccl.comm, as_stream(stream)) != ncclSuccessV) return QMG_ERR_HIP;
   return QMG_SUCCESS;
@@ -96,7 +99,7 @@ int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream) {
 
 int qmg_comm_finalize(void) {
   if (g_rccl.comm) { g_rccl.comm_destroy(g_rccl.comm); g_rccl.comm = nullptr; }
-  g_rccl.world = 1; g_rccl.rank = 0;
+  g_rccl.world = 1; g_rccl.rank = 0; g_rccl.force = false;
   return QMG_SUCCESS;
 }
 

@@ -207,3 +207,24 @@ def test_stencil_apply_with_f32_stored_matrices(nc, nrhs, mask):
     import ctypes as C
     d2 = qmg.make_desc(Lx, Ly, 2, dc32, dh32)
     assert qmg.lib().qmg_stencil_apply_mat32(C.byref(d2), C.c_void_p(dc.ptr), C.c_void_p(dh.ptr), C.c_uint(0xFFF), 1, C.c_size_t(0), C.c_uint(1), None) == 3
+
+
+def test_rccl_allreduce_through_the_c_abi(monkeypatch):
+    """qmg_comm_* (csrc/qmg_comm.hip): librccl is dlopen'ed, a ONE-rank communicator is created for real
+    (QMG_COMM_FORCE_RCCL), and the in-place sum all-reduce of a small double vector in HBM returns the vector -- this pins
+    the hand-declared RCCL signatures and enum values (ncclDouble = 8, ncclSum = 0) against the library on the box.
+    (Two ranks need two GPUs: the multi-rank logic runs on gloo in tests/test_distributed_cpu.py.)"""
+    import ctypes as C
+    monkeypatch.setenv("QMG_COMM_FORCE_RCCL", "1")
+    L = qmg.lib()
+    uid = (C.c_char * 128)()
+    assert L.qmg_comm_get_unique_id(uid) == 0
+    assert L.qmg_comm_init(uid, 1, 0) == 0
+    w, r = C.c_int(-1), C.c_int(-1)
+    assert L.qmg_comm_world(C.byref(w), C.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    vals = np.arange(1.0, 9.0) * 0.125 + 1j * np.arange(8.0)          # 16 doubles
+    d = D(vals)
+    assert L.qmg_allreduce_sum_f64(C.c_void_p(d.ptr), C.c_size_t(16), None) == 0
+    qmg.sync()
+    assert np.array_equal(d.to_host(), vals)
+    assert L.qmg_comm_finalize() == 0
