@@ -228,3 +228,31 @@ def test_rccl_allreduce_through_the_c_abi(monkeypatch):
     qmg.sync()
     assert np.array_equal(d.to_host(), vals)
     assert L.qmg_comm_finalize() == 0
+
+
+def test_batch_entry_points_edge_cases():
+    """Empty masks and empty vectors are no-ops; one-system batches equal the single-vector calls; bad arguments are
+    refused with a status, not a crash."""
+    import ctypes as C
+    L = qmg.lib()
+    n, nrhs = 33, 3
+    x = cs.gaussian_cvec(n * nrhs, 1)
+    y0 = cs.gaussian_cvec(n * nrhs, 2)
+    dx, dy = D(x), D(y0)
+    qmg.batch_blas(qmg.BOP_CAXPY, dy, n, nrhs, n, 0, a=[1.0, 2.0, 3.0], x=dx)          # mask 0: nothing happens
+    assert np.array_equal(dy.to_host(), y0)
+    qmg.batch_blas(qmg.BOP_CAXPY, dy, 0, nrhs, n, 0b111, a=[1.0, 2.0, 3.0], x=dx)      # n = 0: nothing happens
+    assert np.array_equal(dy.to_host(), y0)
+    out = qmg.batch_reduce(qmg.BRED_NORM2, dx, None, n, nrhs, n, 0)
+    assert np.all(np.isnan(out.real))
+    one = qmg.batch_reduce(qmg.BRED_NORM2, dx, None, n, 1, n, 1)                        # one-system batch == single call
+    assert one[0].real == qmg.norm2sq(D(x[:n]), n)
+    # refused, not crashed
+    assert L.qmg_batch_blas(99, None, None, C.c_void_p(dx.ptr), None, C.c_void_p(dy.ptr), C.c_size_t(n), nrhs, C.c_size_t(n), C.c_uint(1), None) == 1
+    assert L.qmg_batch_blas(qmg.BOP_COPY, None, None, C.c_void_p(dx.ptr), None, C.c_void_p(dy.ptr), C.c_size_t(n), 17, C.c_size_t(n), C.c_uint(1), None) == 1
+    assert L.qmg_batch_reduce(qmg.BRED_DOT, C.c_void_p(dx.ptr), None, C.c_size_t(n), nrhs, C.c_size_t(n), C.c_uint(1), (C.c_double * 6)(), None) == 1
+    d = qmg.make_desc(8, 8, 8, dx, dx)
+    assert L.qmg_stencil_apply_batch(C.byref(d), C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), C.c_uint(0xFFF), 17, C.c_size_t(n), C.c_uint(1), None) == 1
+    assert L.qmg_stencil_apply_batch(C.byref(d), C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), C.c_uint(0xFFF), 4, C.c_size_t(8 * 8 * 8), C.c_uint(0), None) == 0   # empty mask
+    free_b, total_b = C.c_size_t(0), C.c_size_t(0)
+    assert L.qmg_mem_info(C.byref(free_b), C.byref(total_b)) == 0 and 0 < free_b.value <= total_b.value and total_b.value > 200e9   # 288 GB part
