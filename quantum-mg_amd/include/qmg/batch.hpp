@@ -240,7 +240,11 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi
       if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * eps * bnorm[k]) renorm |= 1u << k;
     }
     qmg::bcaxpy(alpha, r, phi, size, upd);
-    qmg::bcaxpy(malpha, p, r, size, upd);
+    // r is only needed by a further iteration or by a true-norm re-anchoring: the residual update of a system's LAST
+    // iteration is skipped (the K-cycle recomputes b - A x itself); x and the returned analytic |r|^2 are unaffected
+    unsigned need_r = renorm;
+    for (int k = 0; k < nrhs; k++) if (qmg::is_active(upd, k) && its[k] + 1 < max_iter) need_r |= 1u << k;
+    qmg::bcaxpy(malpha, p, r, size, upd & need_r);
     if (renorm) {
       const std::vector<double> t = qmg::bnorm2sq(r, size, renorm);
       for (int k = 0; k < nrhs; k++) if (qmg::is_active(renorm, k)) { rsq[k] = t[k]; rsq_ref[k] = t[k]; }

@@ -132,10 +132,13 @@ inline inversion_info minv_vector_minres(complex<double>* phi, complex<double>* 
     if (pp == 0.0) break;
     const complex<double> alpha = omega * pr / pp;
     caxpy(alpha, r, phi, size);
-    caxpy(-alpha, p, r, size);
     // (the subtraction loses absolute accuracy ~1e-16 * rsq_ref: re-anchor with a true norm after every 8 orders of magnitude)
     rsq = rsq - (2.0 * omega - omega * omega) * std::norm(pr) / pp;
-    if (!(rsq > 1e-8 * rsq_ref) || std::sqrt(rsq) < 4.0 * eps * bnorm) { rsq = norm2sq(r, size); rsq_ref = rsq; }
+    const bool renorm = !(rsq > 1e-8 * rsq_ref) || std::sqrt(rsq) < 4.0 * eps * bnorm;
+    // r is only needed by a further iteration or by the re-anchoring: the residual update of the LAST iteration is skipped
+    // (callers that want the residual recompute b - A x, as the K-cycle does); x and the returned |r|^2 are unaffected
+    if (renorm || k + 1 < max_iter) caxpy(-alpha, p, r, size);
+    if (renorm) { rsq = norm2sq(r, size); rsq_ref = rsq; }
     k++;
     qmg::report(verb, "MinRes", k, std::sqrt(rsq) / bnorm);
     if (std::sqrt(rsq) < eps * bnorm) conv = true;
