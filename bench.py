@@ -246,6 +246,8 @@ def kcycle_c3_batched(nrhs=8):
     exe = os.path.join(drivers, "n13_wilson_kcycle_mrhs")
     fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
     try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
         p = subprocess.run([exe, "2048", str(MASS), "6.0", "2", "24", fixture, "64", str(nrhs)], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
                            capture_output=True, text=True, timeout=600)
         m = re.search(r"setup ([\d.e+-]+) s ; batched solve of (\d+) systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+) ; systems/s ([\d.e+-]+)", p.stdout)
@@ -268,6 +270,8 @@ def kcycle_c5_shape():
     exe = os.path.join(drivers, "n22_wilson_kcycle_adaptive")
     fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
     try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
         p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
                            capture_output=True, text=True, timeout=600)
         m = re.search(r"setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
