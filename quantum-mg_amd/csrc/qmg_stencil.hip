@@ -510,6 +510,160 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
   }
 }
 
+// Kernel B32 (opt-in complex<float> matrix storage, even nc): kernel B with the tile kept in fp32 end to end -- 16-B
+// loads carry two matrix elements, the staging registers and the LDS tile hold raw float pairs (half the registers, half
+// the LDS: twice the resident blocks), and an element is widened to fp64 only when it is multiplied.  PP = staged PAIRS per
+// thread.  Row stride nc + 2 floats-pairs: even (16-B aligned pair stores) and conflict-free for the 8-byte row reads.
+template <int PP, int KR>
+__global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, const int nc, const GenLayout L) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int rs32 = nc + 2;
+  float2* mlds = reinterpret_cast<float2*>(smem_raw);                                     // [S*nc rows][rs32] complex<float>
+  cplx* xlds = reinterpret_cast<cplx*>(smem_raw + (((size_t)L.S * nc * rs32 * 8 + 15) & ~(size_t)15));   // [KR][S][nc]
+  cplx* red = xlds + (size_t)KR * L.S * nc;                                               // [H][S*nc]
+
+  const int tid = threadIdx.x;
+  const int rows = L.S * nc;             // (s, r) pairs in this block
+  const int h = tid / rows;              // slice id (threads beyond H*rows idle in the compute phase)
+  const int sr = tid - h * rows;
+  const bool worker = h < L.H;
+  const int s_of = sr / nc;
+  const int r_of = sr - s_of * nc;
+  const int cchunk = (nc + L.H - 1) / L.H;
+  const int c0 = h * cchunk;
+  const int c1 = (c0 + cchunk < nc) ? c0 + cchunk : nc;
+
+  const int j0 = blockIdx.x * L.S;
+  const int nsite = (a.hr - j0 < L.S) ? a.hr - j0 : L.S;    // ragged last tile
+  const long nc2 = (long)nc * nc;
+
+  for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
+    const int y = (a.par_count == 2) ? (row >> 1) : row;
+    const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
+    const unsigned hop_mask = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
+    const bool do_shift = (a.pieces >> (10 + p)) & 1u;
+    const bool do_zero = (a.pieces >> (12 + p)) & 1u;
+    const unsigned piece_mask = hop_mask | (do_clover ? 16u : 0u);   // bit 4 = clover
+
+    const long site0 = (long)p * a.half_vol + (long)y * a.hr + j0;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const int s = (y + p) & 1;
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
+    const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+
+    for (int k0 = 0; k0 < a.nrhs; k0 += KR) {
+      const int nk = (a.nrhs - k0 < KR) ? a.nrhs - k0 : KR;
+      cplx acc[KR];
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) acc[kk] = cmake(0.0, 0.0);
+
+      // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
+      const int order[5] = {4, 0, 1, 2, 3};
+      double2 stage[PP];   // raw bits of two complex<float> each
+      cplx xstage[KR];
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) xstage[kk] = cmake(0.0, 0.0);
+      int cur = -1;
+      // find first active piece and prefetch it
+      int oi = 0;
+      while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
+      auto prefetch = [&](int piece) {
+        const cplx* mbase = (piece == 4) ? a.clover : a.hopping;                 // (element offsets, so that the same
+        long moff = (piece == 4) ? site0 * nc2 : (long)piece * a.size_cm + site0 * nc2;   //  code serves both matrix widths)
+        const int lim = nsite * (int)nc2;
+        const float2* m32 = reinterpret_cast<const float2*>(mbase) + moff;
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+          const int el = 2 * (tid + q * BLOCK);
+          if (el < lim) {
+            const double* pp = reinterpret_cast<const double*>(m32 + el);
+            stage[q].x = __builtin_nontemporal_load(pp);
+            stage[q].y = __builtin_nontemporal_load(pp + 1);
+          } else stage[q] = make_double2(0.0, 0.0);
+        }
+        // neighbour vector element for (site, c) = tid / nc, tid % nc
+        if (tid < nsite * nc) {
+          const int sl = tid / nc, cc = tid - sl * nc;
+          const int j = j0 + sl;
+          long nbsite;
+          if (piece == 4) nbsite = site0 + sl;
+          else if (piece == 0) { int jp = j + s; if (jp == a.hr) jp = 0; nbsite = opp + (long)y * a.hr + jp; }
+          else if (piece == 1) nbsite = opp + (long)yp * a.hr + j;
+          else if (piece == 2) { int jm = j + s - 1; if (jm < 0) jm = a.hr - 1; nbsite = opp + (long)y * a.hr + jm; }
+          else nbsite = opp + (long)ym * a.hr + j;
+#pragma unroll
+          for (int kk = 0; kk < KR; kk++)
+            if (kk < nk) xstage[kk] = a.rhs[rhs_offset(a, k0 + kk) + nbsite * nc + cc];
+        }
+      };
+      if (oi < 5) { cur = order[oi]; prefetch(cur); }
+
+      while (cur >= 0) {
+        __syncthreads();   // previous compute finished reading LDS
+        // registers -> LDS (padded rows)
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+          const int el = 2 * (tid + q * BLOCK);
+          if (el < L.mat_elems) {   // (nc even: the pair never straddles a row; rs32 and cc even: 16-B aligned)
+            const int rowi = el / nc, cc = el - rowi * nc;
+            *reinterpret_cast<double2*>(mlds + (size_t)rowi * rs32 + cc) = stage[q];
+          }
+        }
+        if (tid < L.S * nc) {
+#pragma unroll
+          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[kk];
+        }
+        // issue the next piece's global loads before computing on this one
+        int nxt = -1;
+        oi++;
+        while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
+        if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
+        __syncthreads();
+        if (worker && s_of < nsite && !(a.ablate & 32)) {
+          const float2* mrow = mlds + (size_t)sr * rs32;
+          const cplx* xs = xlds + s_of * nc;
+          for (int cc = c0; cc < c1; cc++) {
+            const float2 mf = mrow[cc];       // one 8-B LDS read serves all KR right-hand sides; widened here
+            const cplx m = make_double2((double)mf.x, (double)mf.y);
+#pragma unroll
+            for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
+          }
+        }
+        if (a.ablate & 32) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
+        cur = nxt;
+      }
+
+      // shift term needs the own-site vector
+      if (do_shift && worker && h == 0 && s_of < nsite) {
+        const double sg = p ? -1.0 : 1.0;
+        const double dg = (nc % 2 == 0) ? ((r_of < nc / 2) ? 1.0 : -1.0) : 0.0;
+        const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
+                              a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+#pragma unroll
+        for (int kk = 0; kk < KR; kk++)
+          if (kk < nk) cmac(acc[kk], sh, a.rhs[rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of]);
+      }
+      // sum the H slices, one right-hand side at a time through the same LDS buffer
+#pragma unroll
+      for (int kk = 0; kk < KR; kk++) {
+        if (kk >= nk) break;
+        __syncthreads();
+        if (worker) red[(size_t)h * rows + sr] = acc[kk];
+        __syncthreads();
+        if (h == 0 && s_of < nsite) {
+          cplx t = red[sr];
+          for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
+          cplx* out = a.lhs + rhs_offset(a, k0 + kk);
+          const long o = (site0 + s_of) * nc + r_of;
+          if (!do_zero) t = cadd(out[o], t);
+          out[o] = t;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Kernel C (nc in {8,12,16,24,32}, 2..16 right-hand sides per pass): the coarse apply as a real contraction on the f64
 // matrix cores.  With k right-hand sides against one matrix read the per-site work is the (nc x nc) . (nc x k) product
@@ -708,6 +862,7 @@ static int g_stencil_ablate = 0;
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
+static int g_gen32 = 1;          // tuning knob: fp32-stored matrices, even nc: 1 = kernel B32 (fp32 tile end to end), 2 = same with 2-site tiles, 0 = kernel B with widening loads
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
 static GenLayout make_gen_layout(int nc, int hr, int mat32) {
@@ -743,6 +898,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
@@ -902,6 +1058,28 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   }
 
   if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
+  if (a.mat32 && !(nc & 1) && g_gen32) {
+    // kernel B32: fp32 tile end to end (even nc)
+    const GenLayout L = make_gen_layout(nc, a.hr, g_gen32 == 2 ? 1 : 0);
+    const int pp = (L.mat_elems / 2 + BLOCK - 1) / BLOCK;
+    if (pp >= 1 && pp <= 6) {
+      int kr = (a.nrhs >= 5) ? 8 : (a.nrhs >= 2) ? 4 : 1;
+      auto smem_of = [&](int k) { return (((size_t)L.S * nc * (nc + 2) * 8 + 15) & ~(size_t)15) + sizeof(cplx) * ((size_t)k * L.S * nc + (size_t)L.H * L.S * nc); };
+      while (kr > 1 && smem_of(kr) > 48 * 1024) kr = (kr == 8) ? 4 : 1;
+      const size_t smem = smem_of(kr);
+      if (smem <= 64 * 1024) {
+        const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
+        dim3 grid(gx, gy), block(BLOCK);
+#define QMG_G32_CASE2(PP, KR) k_stencil_gen32<PP, KR><<<grid, block, smem, st>>>(a, nc, L);
+#define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else { QMG_G32_CASE2(PP, 1) } } break;
+        switch (pp) { QMG_G32_CASE(1) QMG_G32_CASE(2) QMG_G32_CASE(3) QMG_G32_CASE(4) QMG_G32_CASE(5) QMG_G32_CASE(6) default: break; }
+#undef QMG_G32_CASE
+#undef QMG_G32_CASE2
+        QMG_LAUNCH_CHECK();
+        return QMG_SUCCESS;
+      }
+    }
+  }
   const GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
   // right-hand sides per pass of kernel B: as many as there are, up to 8 (accumulators) and what LDS holds
