@@ -701,12 +701,16 @@ template <int NC, int MODE, bool M32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, const int nk) {
   constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
   constexpr int NACC = 2;
-  constexpr int RS = NC + 1;                      // LDS row stride (complex), odd
+  // LDS row stride in tile elements: fp64 tile nc+1 complex (odd: conflict-free 16-B reads); fp32-stored matrices keep the
+  // tile as raw complex<float> with stride nc+2 (even: 16-B aligned pair stores) -- half the LDS and half the staging
+  // registers, widened to fp64 only as an MFMA operand
+  constexpr int RS = M32 ? NC + 2 : NC + 1;
   constexpr int NC2 = NC * NC;
   constexpr int NG = (NC2 + WAVE - 1) / WAVE;     // staged 16-B elements per lane per piece
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-  cplx* mlds = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * NC * RS;
+  cplx* mlds = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * NC * RS;                // fp64 tile
+  float2* mlds32 = reinterpret_cast<float2*>(smem_raw) + (size_t)wave * NC * RS;          // fp32 tile (M32)
   const int lr = lane & 15, lq = lane >> 4;
   const int j = blockIdx.x * (BLOCK / WAVE) + wave;
   if (j >= a.hr) return;                      // whole wavefront leaves; the kernel has no block barriers
@@ -740,18 +744,21 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
       for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     constexpr int NGP = (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS per lane per piece (fp32-stored matrices)
-    cplx G[M32 ? 2 * NGP : NG];
+    cplx G[M32 ? NGP : NG];   // M32: raw bits of two complex<float> per entry
     // MODE 1 needs only the half of X its column carries (re for columns 0-7, im for 8-15): one double per k-step
     typename std::conditional<MODE == 1, double, cplx>::type B[2][KS];
     auto load_piece = [&](int pc, int set) {      // global -> registers: matrix (lane-linear) and the k right-hand sides
       const cplx* mbase = (pc == 0) ? a.clover : a.hopping;
       const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * NC2;
-      if (M32) {   // pairs of complex<float>: 16 B per lane per load
+      if (M32) {   // pairs of complex<float>: 16 B per lane per load, kept as raw bits
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
           const int el = 2 * (g * WAVE + lane);
-          if (NC2 % (2 * WAVE) == 0 || el < NC2) ldm32_pair<true>(mbase, moff + el, G[2 * g], G[2 * g + 1]);
-          else { G[2 * g] = cmake(0.0, 0.0); G[2 * g + 1] = cmake(0.0, 0.0); }
+          if (NC2 % (2 * WAVE) == 0 || el < NC2) {
+            const double* pp = reinterpret_cast<const double*>(reinterpret_cast<const float2*>(mbase) + moff + el);
+            G[g].x = __builtin_nontemporal_load(pp);
+            G[g].y = __builtin_nontemporal_load(pp + 1);
+          } else G[g] = cmake(0.0, 0.0);
         }
       } else {
 #pragma unroll
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
           const int el = 2 * (g * WAVE + lane);
-          if (NC2 % (2 * WAVE) == 0 || el < NC2) { mlds[(el / NC) * RS + (el % NC)] = G[2 * g]; mlds[(el / NC) * RS + (el % NC) + 1] = G[2 * g + 1]; }
+          if (NC2 % (2 * WAVE) == 0 || el < NC2) *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[g];   // 16-B aligned: RS, el even
         }
       } else {
 #pragma unroll
@@ -793,7 +800,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 #pragma unroll
         for (int t = 0; t < RT; t++) {
           const int r = 16 * t + lr, c = 4 * q + lq;
-          Af[t] = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds[r * RS + c] : cmake(0.0, 0.0);
+          if (M32) {
+            const float2 mf = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds32[r * RS + c] : make_float2(0.0f, 0.0f);
+            Af[t] = cmake((double)mf.x, (double)mf.y);
+          } else
+            Af[t] = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds[r * RS + c] : cmake(0.0, 0.0);
         }
         if constexpr (MODE == 0) {
 #pragma unroll
@@ -1032,7 +1043,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       b.lhs = a.lhs + (long)k0 * a.vec_stride;
       b.rhs = a.rhs + (long)k0 * a.vec_stride;
       const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
-      const size_t smem = sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
+      const size_t smem = a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * nc * (nc + 2) : sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
       const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
 #define QMG_MFMA_LAUNCH1(NC, MODE, M32)                                                                         \
       {                                                                                                         \
