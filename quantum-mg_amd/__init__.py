@@ -131,6 +131,13 @@ class DeviceArray:
         check(lib().qmg_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), None), "d2h")
         return out
 
+    def read(self, first, count):
+        """`count` elements starting at element `first`, copied to the host (spot checks on arrays too large to download)."""
+        out = np.empty(int(count), dtype=self.dtype)
+        sync()
+        check(lib().qmg_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.offset(first)), C.c_size_t(out.nbytes), None), "d2h")
+        return out
+
     def upload(self, a):
         a = np.ascontiguousarray(a, dtype=self.dtype)
         assert a.size == self.n

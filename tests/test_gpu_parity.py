@@ -534,3 +534,56 @@ def test_coarse_build_matches_oracle_and_n08_galerkin(fdims, cdims):
     gcd = qmg.make_desc(cdims[0], cdims[1], cdims[2], gcc, gch, 0.1)    # shift copied, coarse.h:131
     qmg.stencil_apply(gcd, direct, dvc)
     assert cs.rel_l2(direct.to_host(), emul.to_host()) < 1e-12
+
+
+def test_coarse_apply_beyond_2_31_matrix_elements_spot_checked():
+    """Maximum sizes: 1024^2 with nc = 24 has 4 * 1024^2 * 576 = 2.4e9 hopping elements -- where the reference's `int
+    size_hopping` overflows (lattice.h:23,40).  48 GB of random matrices are generated on the device; the output of one
+    apply (kernel B), and of a 5-rhs batch (kernel C, f64 MFMA), is checked at sampled sites -- first, last, row ends,
+    random -- against a host computation from the rows of the five matrices and the neighbour vectors fetched for those
+    sites.  Size-independent, exact to 1e-13."""
+    L, nc = 1024, 24
+    vol, hr, half = L * L, L // 2, L * L // 2
+    nc2 = nc * nc
+    cl = qmg.DeviceArray(vol * nc2); qmg.gaussian(cl, vol * nc2, 11)
+    ho = qmg.DeviceArray(4 * vol * nc2); qmg.gaussian(ho, 4 * vol * nc2, 12)
+    nrhs = 5
+    x = qmg.DeviceArray(nrhs * vol * nc); qmg.gaussian(x, nrhs * vol * nc, 13)
+    y1 = qmg.DeviceArray(vol * nc)
+    yb = qmg.DeviceArray(nrhs * vol * nc)
+    shift = 0.3 - 0.2j
+    d = qmg.make_desc(L, L, nc, cl, ho, shift)
+    qmg.stencil_apply(d, y1, x, qmg.P_ALL | qmg.P_ZERO)
+    qmg.stencil_apply_batch(d, yb, x, qmg.P_ALL | qmg.P_ZERO, nrhs, vol * nc, (1 << nrhs) - 1)
+    rng = np.random.default_rng(5)
+    samples = [(0, 0, 0), (1, L - 1, hr - 1), (0, L - 1, 0), (1, 0, hr - 1), (0, 511, 255), (1, 512, 256)]
+    samples += [(int(rng.integers(2)), int(rng.integers(L)), int(rng.integers(hr))) for _ in range(10)]
+    for p, y, j in samples:
+        site = p * half + y * hr + j
+        s = (y + p) & 1
+        opp = (1 - p) * half
+        nb = [site, opp + y * hr + (j + s) % hr, opp + ((y + 1) % L) * hr + j, opp + y * hr + (j + s - 1) % hr, opp + ((y - 1) % L) * hr + j]
+        mats = [cl.read(site * nc2, nc2).reshape(nc, nc)] + [ho.read(mu * vol * nc2 + site * nc2, nc2).reshape(nc, nc) for mu in range(4)]
+        for k in range(nrhs):
+            vecs = [x.read(k * vol * nc + n * nc, nc) for n in nb]
+            want = sum(m @ v for m, v in zip(mats, vecs)) + shift * vecs[0]
+            got_b = yb.read(k * vol * nc + site * nc, nc)
+            assert cs.rel_l2(got_b, want) < TOL, (p, y, j, k)
+            if k == 0:
+                assert cs.rel_l2(y1.read(site * nc, nc), want) < TOL, (p, y, j)
+    for a in (cl, ho, x, y1, yb):
+        a.free()
+
+
+def test_wilson_apply_8192_periodic_image(golden_dir):
+    """Maximum sizes for the fine operator: 8192^2 (67M sites, 17 GiB of hopping matrices).  The 64-periodic gauge field
+    with a 64-periodic right-hand side must give the 64-periodic image of the oracle's 64^2 result (bench.py's gate)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fixture = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    wl = bench.Workload(qmg, 8192, fixture, seed=7)
+    try:
+        assert wl.parity_gate(fixture) < TOL
+    finally:
+        wl.free()
