@@ -587,3 +587,42 @@ def test_wilson_apply_8192_periodic_image(golden_dir):
         assert wl.parity_gate(fixture) < TOL
     finally:
         wl.free()
+
+
+def test_transfer_at_4096_spot_checked():
+    """Maximum sizes for the transfer: 4096^2 (nc 2) -> 1024^2 (nc 24): 24 null vectors of 33.5M complex (12.9 GB, byte
+    offsets far beyond 2^32).  prolong and restrict outputs are checked at sampled sites against a host computation from
+    the fetched null-vector entries (blocks = 4x4 fine sites, transfer.h:391-395)."""
+    fL, cL, fnc, cnc = 4096, 1024, 2, 24
+    fsize, csize = fL * fL * fnc, cL * cL * cnc
+    nv = qmg.DeviceArray(cnc * fsize); qmg.gaussian(nv, cnc * fsize, 21)
+    cv = qmg.DeviceArray(csize); qmg.gaussian(cv, csize, 22)
+    fv = qmg.DeviceArray(fsize); qmg.gaussian(fv, fsize, 23)
+    fout = qmg.DeviceArray.zeros(fsize)
+    cout = qmg.DeviceArray.zeros(csize)
+    fd, cd = (fL, fL, fnc), (cL, cL, cnc)
+    qmg.prolong(nv, cnc, cv, fout, fd, cd)
+    qmg.restrict(nv, cnc, fv, cout, fd, cd)
+    fidx = lambda x, y: ((y + ((x + y) & 1) * fL) * (fL // 2) + x // 2)
+    cidx = lambda x, y: ((y + ((x + y) & 1) * cL) * (cL // 2) + x // 2)
+    rng = np.random.default_rng(9)
+    coarse_sites = [(0, 0), (cL - 1, cL - 1), (cL - 1, 0), (511, 512)] + [(int(rng.integers(cL)), int(rng.integers(cL))) for _ in range(3)]
+    for cx, cy in coarse_sites:
+        ci = cidx(cx, cy)
+        cvals = cv.read(ci * cnc, cnc)
+        # restrict: coarse[ci, d] = sum over the 4x4 block of conj(null[d][e]) fine[e]
+        want = np.zeros(cnc, dtype=np.complex128)
+        block = [(4 * cx + dx, 4 * cy + dy) for dy in range(4) for dx in range(4)]
+        for (x, y) in block:
+            e0 = fidx(x, y) * fnc
+            f = fv.read(e0, fnc)
+            for dd in range(cnc):
+                want[dd] += np.vdot(nv.read(dd * fsize + e0, fnc), f)
+        assert cs.rel_l2(cout.read(ci * cnc, cnc), want) < TOL, (cx, cy)
+        # prolong at two fine sites of the block: fine[e] = sum_d null[d][e] coarse[ci, d]
+        for (x, y) in (block[0], block[-1]):
+            e0 = fidx(x, y) * fnc
+            wantf = sum(nv.read(dd * fsize + e0, fnc) * cvals[dd] for dd in range(cnc))
+            assert cs.rel_l2(fout.read(e0, fnc), wantf) < TOL, (x, y)
+    for a in (nv, cv, fv, fout, cout):
+        a.free()
