@@ -876,7 +876,7 @@ static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc i
 static int g_gen32 = 1;          // tuning knob: fp32-stored matrices, even nc: 1 = kernel B32 (fp32 tile end to end), 2 = same with 2-site tiles, 0 = kernel B with widening loads
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
-static GenLayout make_gen_layout(int nc, int hr, int mat32) {
+static GenLayout make_gen_layout(int nc, int hr, int mat32, int site_cap = 0) {
   GenLayout L;
   const int nc2 = nc * nc;
   int S = (BLOCK * GEN_MAX_PER_THREAD) / nc2;       // registers: S*nc^2 <= 256*12
@@ -886,6 +886,7 @@ static GenLayout make_gen_layout(int nc, int hr, int mat32) {
   // half the bytes per piece, smaller tiles (more resident blocks) pay: 512^2, nc = 24: S = 5 1.81 ms, S = 2 1.59 ms
   if (mat32 && nc >= 16 && S > 2) S = 2;
   if (g_gen_sites > 0 && S > g_gen_sites) S = g_gen_sites;
+  if (site_cap > 0 && S > site_cap) S = site_cap;
   if (S < 1) S = 1;
   L.S = S;
   int H = BLOCK / (S * nc);
@@ -1034,7 +1035,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   // several right-hand sides against one matrix read: kernel C (f64 MFMA) from 4 systems up -- measured 512^2 nc = 24, 8 rhs:
   // 2.84 ms against 4.84 ms for the vector-FMA kernel B, which tops out near 10 TFLOP/s on LDS traffic; with 2-3 systems
   // kernel B's shared tile wins (nc = 8, 1024^2, 3 rhs: 1.06 vs 1.39 ms) and it serves every other nc
-  if (a.nrhs >= 4 && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
+  // (nc <= 16: kernel B with one 4-accumulator pass still wins at exactly 4 systems -- nc = 8, 1024^2: 1.21 vs 1.52 ms;
+  //  nc = 16, 512^2: 0.98 vs 1.08 ms -- so there the matrix cores take over from 5)
+  if (a.nrhs >= (nc <= 16 ? 5 : 4) && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
     // kernel C: up to 16 right-hand sides per pass share one read of the matrices
     const unsigned gx = (unsigned)((a.hr + BLOCK / WAVE - 1) / (BLOCK / WAVE));
     dim3 grid(gx, gy), block(BLOCK);
@@ -1091,15 +1094,15 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       }
     }
   }
-  const GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
+  GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
-  // right-hand sides per pass of kernel B: as many as there are, up to 8 (accumulators) and what LDS holds
+  // right-hand sides per pass of kernel B: 4 (2-4 systems) or 8 accumulators; if the tile plus the vectors of the pass do
+  // not fit 64 KB of LDS (>= 2 blocks per CU) the tile shrinks first (nc = 16: 12 -> 6 sites), the pass second
   int kr = (a.nrhs >= 5) ? 8 : (a.nrhs >= 2) ? 4 : 1;
-  size_t smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)kr * L.S * nc + (size_t)L.H * L.S * nc);
-  while (kr > 1 && smem > 64 * 1024) {   // keep >= 2 blocks per CU
-    kr = (kr == 8) ? 4 : 1;
-    smem = sizeof(cplx) * ((size_t)L.S * nc * L.rs + (size_t)kr * L.S * nc + (size_t)L.H * L.S * nc);
-  }
+  auto smem_of = [&](const GenLayout& l, int k) { return sizeof(cplx) * ((size_t)l.S * nc * l.rs + (size_t)k * l.S * nc + (size_t)l.H * l.S * nc); };
+  while (kr > 1 && smem_of(L, kr) > 64 * 1024 && L.S > 1) L = make_gen_layout(nc, a.hr, a.mat32, (L.S + 1) / 2);
+  while (kr > 1 && smem_of(L, kr) > 64 * 1024) kr = (kr == 8) ? 4 : 1;
+  const size_t smem = smem_of(L, kr);
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
