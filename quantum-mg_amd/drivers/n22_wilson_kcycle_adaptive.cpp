@@ -15,6 +15,12 @@
 // Solve (n22:494-497): VPGCR tol 1e-10, 1000 its, restart 64, K-cycle preconditioner.  Prints the reference's
 // [QMG-OPS-STATS] / [QMG-ITER-STATS] lines (the reference prints the PreSmooth count under "PostSmooth" too,
 // n22:511; here the PostSmooth count is printed).
+// Several GPUs (SURVEY 8e "setup phase"; not in n22): started one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK in the
+// environment (torchrun sets them), every rank builds the same hierarchy, but the adaptive relaxations of a level are
+// SHARDED over the ranks (test vector j belongs to rank j mod world) and exchanged with ONE sum all-reduce per level
+// (qmg_allreduce_sum_f64, RCCL over xGMI; the vectors a rank does not own are zero in its buffer), after which all ranks
+// continue identically.  The 128-byte RCCL id travels through a file (QMG_COMM_ID_FILE, default /tmp/qmg_comm_id.<port>).
+// In the solve every rank then takes its own right-hand side (seed + rank): the path's "independent right-hand sides".
 // solve_type (optional, not in n22): "schur" builds rbjacobi stencils on every level and solves as n19 does --
 // the "red-black preconditioned" variant of BASELINE configs[4].
 #include <chrono>
@@ -23,6 +29,8 @@
 #include <iomanip>
 #include <iostream>
 #include <string>
+#include <fstream>
+#include <thread>
 
 #include "../include/qmg/qmg.hpp"
 #include "mrhs_solve.hpp"
@@ -88,7 +96,32 @@ int main(int argc, char** argv) {
     return -1;
   }
   cout << setprecision(20);
-  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
+  const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+  const int local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
+  if (!qmg::ok(qmg_init(local_rank), "qmg_init")) return 2;
+  const bool use_comm = world > 1 || getenv("QMG_COMM_FORCE_RCCL") != 0;
+  if (use_comm) {   // rank 0 creates the RCCL id and publishes it through a file; the others wait for it
+    const std::string idfile = getenv("QMG_COMM_ID_FILE") ? std::string(getenv("QMG_COMM_ID_FILE"))
+                                                          : std::string("/tmp/qmg_comm_id.") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "." +
+                                                                (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");   // unique per launch
+    char id[128];
+    if (rank == 0) {
+      if (!qmg::ok(qmg_comm_get_unique_id(id), "qmg_comm_get_unique_id")) return 2;
+      { std::ofstream f((idfile + ".tmp").c_str(), std::ios::binary); f.write(id, 128); }
+      std::rename((idfile + ".tmp").c_str(), idfile.c_str());
+    } else {
+      bool got_id = false;
+      for (int tries = 0; tries < 600 && !got_id; tries++) {
+        std::ifstream f(idfile.c_str(), std::ios::binary);
+        if (f && f.read(id, 128)) got_id = true; else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+      if (!got_id) { cout << "[QMG-ERROR]: rank " << rank << " did not receive the RCCL id through " << idfile << "\n"; return 2; }
+    }
+    if (!qmg::ok(qmg_comm_init(id, world, rank), "qmg_comm_init")) return 2;
+    if (rank == 0 && world > 1) std::this_thread::sleep_for(std::chrono::milliseconds(500));   // let the others read before the file is reused
+    cout << "[QMG-INFO]: rank " << rank << " of " << world << " on device " << local_rank << "\n";
+  }
   if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   const int x_len = stoi(argv[1]), y_len = x_len;
   const double mass = stod(argv[2]);
@@ -211,10 +244,17 @@ int main(int argc, char** argv) {
         }
         qmg::bzero(X, n, all);
         inversion_verbose_struct vq(VERB_NONE, "");
+        unsigned mine = 0;   // the systems this rank relaxes: j mod world == rank
+        for (int j = 0; j < nb; j++) if (j % world == rank) mine |= 1u << j;
         std::vector<inversion_info> binv = bgcr_core(X, T, (int)n, 10, 1e-10, -1, apply_stencil_2D_M_batch, (void*)mg_object->get_stencil(fine_idx),
-                                                     mg_preconditioner_batch, (void*)&bk, all, true, &vq, "VPGCR");
+                                                     mg_preconditioner_batch, (void*)&bk, mine, true, &vq, "VPGCR");
+        if (use_comm) {   // one collective per level: everybody gets every relaxed vector (foreign slots of X are still zero here)
+          if (!qmg::ok(qmg_allreduce_sum_f64((double*)X.p, (size_t)2 * X.stride * nb, qmg::current_stream()), "qmg_allreduce_sum_f64")) return 2;
+          qmg_stream_sync(qmg::current_stream());
+        }
         for (int j = 0; j < nb; j++) {
           copy_vector(test_vectors[fine_idx][j], X.vec(j), n);
+          if (!qmg::is_active(mine, j)) continue;   // relaxed (and reported) by another rank
           mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, binv[j].ops_count + 1, fine_idx);
           cout << "[QMG-SETUP]: pass " << m << " level " << fine_idx << " test vector " << j << ": " << binv[j].iter << " K-cycle iterations, residual "
                << sqrt(binv[j].resSq) << ", t = " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count() << " s (batched)" << std::endl;
@@ -269,6 +309,7 @@ int main(int argc, char** argv) {
 
   const long n0 = lats[0]->get_size_cv_l();
   complex<double>* b = mg_object->check_out(0);
+  g_seed += (unsigned long long)rank;   // independent right-hand sides: one per rank
   gaussian(b, n0, g_seed++);
   const double bnorm = sqrt(norm2sq(b, n0));
   complex<double>* x = mg_object->check_out(0);
@@ -321,5 +362,6 @@ int main(int argc, char** argv) {
   delete[] lats;
   deallocate_vector(&gauge_field);
   qmg::VecPool::release_all();
+  if (use_comm) qmg_comm_finalize();
   return ok_ ? 0 : 1;
 }

@@ -190,3 +190,20 @@ def test_batched_schur_kcycle_reproduces_the_single_solves(golden_dir):
     assert len(ver) == 3
     for _, single_it, batch_it, diff in ver:
         assert abs(int(single_it) - int(batch_it)) <= 1 and float(diff) < 1e-6
+
+
+def test_n22_rank_sharded_setup_through_rccl(golden_dir, tmp_path):
+    """SURVEY 8e setup phase in the C++ driver: the adaptive relaxations of a level are owned by ranks (j mod world) and
+    exchanged by one RCCL sum all-reduce per level.  One GPU here, so the communicator has one rank -- forced through
+    RCCL (QMG_COMM_FORCE_RCCL), id exchanged through the file as between ranks -- and the run must reproduce the
+    plain run exactly."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    cmd = [os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "128", "-0.07", "6.0", "2", "1", gauge_file, "64"]
+    plain = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=150)
+    forced = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", QMG_COMM_FORCE_RCCL="1", QMG_COMM_ID_FILE=str(tmp_path / "id"),
+                                                       RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=150)
+    assert plain.returncode == 0 and forced.returncode == 0, forced.stdout[-2000:] + forced.stderr[-2000:]
+    assert "rank 0 of 1 on device 0" in forced.stdout
+    pick = lambda out: (re.search(r"Multigrid converged in (\d+) iterations with alleged tolerance ([-\d.e+]+)", out.stdout).groups(),
+                        re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
+    assert pick(plain) == pick(forced)
