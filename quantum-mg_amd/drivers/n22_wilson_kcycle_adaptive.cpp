@@ -31,6 +31,8 @@
 #include <string>
 #include <fstream>
 #include <thread>
+#include <ctime>
+#include <sys/stat.h>
 
 #include "../include/qmg/qmg.hpp"
 #include "mrhs_solve.hpp"
@@ -111,10 +113,17 @@ int main(int argc, char** argv) {
       { std::ofstream f((idfile + ".tmp").c_str(), std::ios::binary); f.write(id, 128); }
       std::rename((idfile + ".tmp").c_str(), idfile.c_str());
     } else {
+      // a file left behind by an earlier launch on the same port must not be taken: accept only one written since shortly
+      // before this process started (the ranks of one launch start within a second of each other)
+      const time_t started = time(0);
       bool got_id = false;
       for (int tries = 0; tries < 600 && !got_id; tries++) {
-        std::ifstream f(idfile.c_str(), std::ios::binary);
-        if (f && f.read(id, 128)) got_id = true; else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        struct stat st;
+        if (stat(idfile.c_str(), &st) == 0 && st.st_mtime >= started - 20) {
+          std::ifstream f(idfile.c_str(), std::ios::binary);
+          if (f && f.read(id, 128)) got_id = true;
+        }
+        if (!got_id) std::this_thread::sleep_for(std::chrono::milliseconds(100));
       }
       if (!got_id) { cout << "[QMG-ERROR]: rank " << rank << " did not receive the RCCL id through " << idfile << "\n"; return 2; }
     }
@@ -362,6 +371,14 @@ int main(int argc, char** argv) {
   delete[] lats;
   deallocate_vector(&gauge_field);
   qmg::VecPool::release_all();
-  if (use_comm) qmg_comm_finalize();
+  if (use_comm) {
+    qmg_comm_finalize();
+    if (rank == 0) {
+      const std::string idfile = getenv("QMG_COMM_ID_FILE") ? std::string(getenv("QMG_COMM_ID_FILE"))
+                                                            : std::string("/tmp/qmg_comm_id.") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "." +
+                                                                  (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");
+      std::remove(idfile.c_str());
+    }
+  }
   return ok_ ? 0 : 1;
 }
