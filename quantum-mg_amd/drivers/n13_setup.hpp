@@ -59,7 +59,8 @@ inline int N13::build(int argc, char** argv) {
     return -1;
   }
   cout << setprecision(20);
-  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
+  // one process per GPU: the launcher's LOCAL_RANK picks the device (torchrun sets it); a single process uses device 0
+  if (!qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
   if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   x_len = stoi(argv[1]); y_len = stoi(argv[1]);
   mass = stod(argv[2]);
