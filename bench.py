@@ -305,8 +305,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--no-kcycle", action="store_true")
-    ap.add_argument("--workload", choices=["wilson", "staggered"], default="wilson",
-                    help="wilson: the headline fine Wilson apply (default); staggered: BASELINE configs[3], 8 rhs per GPU + one all-reduce per step")
+    ap.add_argument("--workload", choices=["wilson", "staggered", "kcycle"], default="wilson",
+                    help="wilson: the headline fine Wilson apply (default); staggered: BASELINE configs[3], 8 rhs per GPU + one all-reduce per step; "
+                         "kcycle: BASELINE configs[2] K-cycle, --nrhs independent systems per GPU in lock step, right-hand sides sharded over ranks (no collective)")
     ap.add_argument("--nrhs", type=int, default=8)
     args = ap.parse_args()
 
@@ -336,6 +337,45 @@ def main():
     fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
     L = args.L
     sharding = importlib.import_module("quantum-mg_amd.sharding")
+    if args.workload == "kcycle":
+        # every rank runs the batched n13 driver on its own GPU (the child takes LOCAL_RANK for the device and RANK for its
+        # share of the right-hand sides); one step = one complete solve of the rank's batch; setup is outside the rate
+        import re
+        import subprocess
+        drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+        exe = os.path.join(drivers, "n13_wilson_kcycle_mrhs")
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+        barrier()
+        p = subprocess.run([exe, "2048", str(MASS), "6.0", "2", "24", fixture, "64", str(args.nrhs)], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
+                           capture_output=True, text=True, timeout=900)
+        m = re.search(r"setup ([\d.e+-]+) s ; batched solve of (\d+) systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+)", p.stdout)
+        rows = re.findall(r"rhs (\d+) (converged|failed to converge) in (\d+) iterations ; alleged tolerance [\d.e+-]+ ; check tolerance ([\d.e+-]+)", p.stdout)
+        ok_run = bool(m) and len(rows) == args.nrhs and all(r[1] == "converged" for r in rows) and p.returncode == 0
+        solve_s = float(m.group(3)) if m else float("inf")
+        iters = sum(int(r[2]) for r in rows)
+        wall = sharding.max_over_ranks(solve_s, dist, "cuda")
+        total_iters = iters
+        if dist is not None:
+            t = torch.tensor([float(iters), 1.0 if ok_run else 0.0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t)
+            total_iters, ok_all = t[0].item(), t[1].item() == world
+        else:
+            ok_all = ok_run
+        out = {"metric": "K-cycle outer iterations per second (aggregate over systems and GPUs)", "value": total_iters / wall, "unit": "iterations/s",
+               "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64 (complex128)", "data": "synthetic",
+               "config": {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, %d systems per GPU in lock step (%d total)" % (args.nrhs, world * args.nrhs),
+                          "lattice": [2048, 2048], "nc": 2, "coarse_nc": 24, "mass": MASS, "rhs_per_gpu": args.nrhs,
+                          "parallelism": "right-hand sides sharded over ranks, batched within a rank, no collective in the solve"},
+               "all_converged": ok_all, "worst_true_residual_rank0": max([float(r[3]) for r in rows]) if rows else None,
+               "setup_s_rank0": float(m.group(1)) if m else None}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "staggered":
         wl = StaggeredMultiRHS(qmg, L, fixture, 1337 + rank, args.nrhs, rank, world, dist, torch)
         gate_err = wl.parity_gate(fixture)
