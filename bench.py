@@ -143,7 +143,8 @@ class StaggeredMultiRHS:
         base = self.norms.data_ptr() + 8 * self.rank * self.nrhs
         for k in range(self.nrhs):
             q.check(q.lib().qmg_norm2sq(C.c_void_p(self.lhs.offset(k * self.vol)), C.c_size_t(self.vol), C.c_void_p(base + 8 * k), None, None))
-        sharding.allgather_by_allreduce(self.norms, self.world * self.nrhs, self.rank, self.world, self.dist)
+        # the buffer is reused from step to step: the slots of the other ranks are cleared before the sum (sharding.py)
+        sharding.allgather_by_allreduce(self.norms, self.world * self.nrhs, self.rank, self.world, self.dist, own=(self.rank * self.nrhs, (self.rank + 1) * self.nrhs))
 
     def parity_gate(self, fixture):
         import oracle_lib as ol

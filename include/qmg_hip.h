@@ -43,6 +43,11 @@ typedef enum {
   QMG_ERR_NO_DEVICE = 4
 } qmg_status;
 
+/* Storage precision of device arrays.  The reference is fp64 only (stencil_2d.h:17-18); QMG_C32 is the fp32 instantiation
+ * BASELINE configs[4] asks for: complex<float> storage of vectors, matrices and null vectors, half the bytes of every
+ * HBM-bound kernel.  Reductions always accumulate and return fp64. */
+typedef enum { QMG_C64 = 0, QMG_C32 = 1 } qmg_dtype;
+
 /* cshift directions / parities: names and values identical to cshift/cshift_2d.h:13-36 */
 typedef enum {
   QMG_CSHIFT_FROM_0 = 1, QMG_CSHIFT_FROM_XP1 = 2, QMG_CSHIFT_FROM_YP1 = 3, QMG_CSHIFT_FROM_XM1 = 4, QMG_CSHIFT_FROM_YM1 = 5,
@@ -226,6 +231,30 @@ int qmg_prolong_batch(const void* nullvecs, int nvec, const void* coarse, void* 
 int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
                        int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
 
+/* ---------------- the path in either storage precision (`_t` = typed) ---------------- */
+/* Same operations as the entry points above with the storage type of EVERY array argument (vectors, matrices in the
+ * descriptor, null vectors) given by `dtype` (qmg_dtype); host-side scalars and reduction results stay double.  With
+ * QMG_C64 they ARE the entry points above.  With QMG_C32: the fine kernels (nc = 1, 2, 4) compute in fp32, the coarse
+ * kernels widen to fp64 in registers (f64 FMA / f64 MFMA) and round once on store, reductions accumulate in fp64.
+ * Parity bar: relative L2 <= 5e-6 per apply against the fp64 oracle on the same (rounded) inputs.
+ * fp32 arrays should be 16-byte aligned with even strides (anything qmg_malloc returns is); otherwise the kernels fall
+ * back to 8-byte accesses.  nrhs <= 16, `mask` selects the active systems (nrhs = 1, mask = 1 for a single vector). */
+int qmg_convert(void* dst, int dst_dtype, const void* src, int src_dtype, size_t n, void* stream);   /* element-wise copy / round / widen */
+int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                        int nrhs, size_t vec_stride, unsigned mask, void* stream);
+int qmg_batch_blas_t(int dtype, int op, const double* a, const double* b, const void* x, const void* y, void* z, size_t n,
+                     int nrhs, size_t stride, unsigned mask, void* stream);
+int qmg_batch_multi_caxpy_t(int dtype, const double* coeffs, const void* const* xs, int nj, void* y, size_t n,
+                            int nrhs, size_t stride, unsigned mask, void* stream);
+int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
+                       double* out_host, void* stream);
+int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
+                         double* out_host, void* stream);
+int qmg_prolong_batch_t(int dtype, const void* nullvecs, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc,
+                        int cLx, int cLy, int cnc, int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream);
+int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
+                         int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
+
 /* ---------------- multi-GPU: independent right-hand sides per rank ---------------- */
 /* The path shards over right-hand sides; every rank holds a replica of the stencil/transfer data and
  * there is no halo exchange.  The one collective is a sum all-reduce (RCCL over xGMI) of a small
@@ -233,12 +262,31 @@ int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* c
  * convergence decision.  Rank 0 creates the 128-byte id and ships it by any host channel. */
 int qmg_comm_get_unique_id(void* id128);
 int qmg_comm_init(const void* id128, int world, int rank);      /* collective; after qmg_init(local_rank) */
+/* qmg_comm_init with the id fetched through the launcher's rendezvous: QMG_COMM_ID_HEX (256 hex digits) if set, else one
+ * TCP exchange with rank 0 on MASTER_ADDR : QMG_COMM_PORT (default MASTER_PORT + 1).  Bounded waits (QMG_COMM_TIMEOUT_S,
+ * default 120 s): a missing rank is an error return, never a hang. */
+int qmg_comm_init_env(int world, int rank);
+int qmg_comm_rendezvous(void* blob128, int world, int rank);   /* the TCP leg alone: rank 0's 128 bytes reach every rank (host only) */
+/* *all_ok = 1 iff every rank passed ok != 0 (one tiny all-reduce): lets an error on one rank stop all ranks together
+ * instead of leaving the others blocked in the next collective. */
+int qmg_comm_all_ok(int ok, int* all_ok);
 int qmg_comm_world(int* world, int* rank);
 int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream);   /* in place, async; no-op when world == 1 */
 int qmg_comm_finalize(void);
 
 /* ---------------- tuning hooks (not part of the reference surface) ---------------- */
-/* key "stencil_nt": 1 = non-temporal loads for the stencil matrices in the nc<=4 kernel. */
+/* Dispatch / codegen knobs, all with the defaults the measurements in profiles/ chose; results never depend on them
+ * beyond summation order.  Unknown keys return QMG_ERR_INVALID.
+ *   "stencil_nt"    bit 0: non-temporal loads of the stencil matrices, bit 1: non-temporal stores, nc <= 4 kernels (3)
+ *   "stencil_pair"  0: one site per lane group (kernel A); 1 / 2: both parities of a column on 1 / 2 rows per lane group (2)
+ *   "stencil_rows"  cap on gridDim.y of the stencil kernels, 0 = one block row per lattice row (0)
+ *   "stencil_mfma"  1: multi-rhs coarse applies (nc in 8,12,16,24,32; >= 4-5 systems) on the f64 matrix cores, 2-MFMA
+ *                   packing for <= 8 systems; 2: plain 4-MFMA products; 0: vector-FMA kernel B only (1)
+ *   "gen_sites"     cap on sites per block of kernel B, 0 = register-limited maximum (0)
+ *   "gen32"         fp32-stored matrices, even nc: 1 = fp32 tile end to end (kernel B32), 2 = same with 2-site tiles,
+ *                   0 = kernel B with widening loads (1)
+ *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
+ * (The ablation switch of tools/variants.py exists only in the tools build, `make DIAG=1`; this library has no such key.) */
 int qmg_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus

@@ -130,6 +130,15 @@ int qo_wilson_kcycle(int L, double mass, int n_refine, int coarse_dof, const dou
                      double tol, int max_iter, int restart, double inner_tol, double coarsest_tol, int n_smooth, double* x_out,
                      double* true_res, long* ops, long* its);
 
+/* the same solve with the outer residual history and the iteration count of every coarsest solve (negative: hit its cap) */
+int qo_wilson_kcycle_history(int L, double mass, int n_refine, int coarse_dof, const double* gauge, const double* const* nullvecs, const double* b,
+                             double tol, int max_iter, int restart, double inner_tol, double coarsest_tol, int n_smooth, double* x_out,
+                             double* true_res, long* ops, long* its, double* hist, int nhist, int* nhist_out, long* chist, int nchist, int* nchist_out);
+/* CPU twins of the Krylov drivers on a stencil operator (kind 0 CG, 1 BiCGStab-L, 2 Richardson, 3 MR, 4 restarted GCR;
+ * op 0: M, 1: M^dagger M with `dag` the dagger stencil).  Returns 1 converged / 0 not / -1 bad kind.  See qmg_oracle_kcycle.cpp. */
+int qo_krylov_solve(int kind, const qo_stencil_desc* d, const qo_stencil_desc* dag, int op, double* x, const double* b, int max_iter, double tol,
+                    int param_i, double param_d, int* iters, double* res_sq, double* hist, int nhist);
+
 /* ---- timing helper for bench.py's cpu_baseline leg ---- */
 double qo_time_apply(const qo_stencil_desc* d, double* lhs, const double* rhs, unsigned pieces, int reps);
 

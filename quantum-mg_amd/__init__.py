@@ -43,7 +43,9 @@ ABI_SYMBOLS = [
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
-    "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
+    "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
+    "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
+    "qmg_prolong_batch_t", "qmg_restrict_batch_t",
 ]
 
 
@@ -398,6 +400,70 @@ def prolong_batch(nullvecs, nvec, coarse, fine, fdims, cdims, nrhs, cstride, fst
 def restrict_batch(nullvecs, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
     check(lib().qmg_restrict_batch(_vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
           "qmg_restrict_batch")
+
+
+# ---------------- either storage precision (`_t` entry points; dtype = C64 | C32) ----------------
+C64, C32 = 0, 1
+NP_DTYPE = {C64: np.complex128, C32: np.complex64}
+
+
+def convert(dst, dst_dtype, src, src_dtype, n):
+    check(lib().qmg_convert(_vp(dst), dst_dtype, _vp(src), src_dtype, C.c_size_t(n), None), "qmg_convert")
+
+
+def stencil_apply_t(dtype, desc, lhs, rhs, pieces, nrhs=1, vec_stride=0, mask=1, stream=None):
+    check(lib().qmg_stencil_apply_t(dtype, C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
+          "qmg_stencil_apply_t")
+
+
+def batch_blas_t(dtype, op, z, n, nrhs, stride, mask, a=None, b=None, x=None, y=None):
+    ca, cb = _coef(a, nrhs), _coef(b, nrhs)
+    check(lib().qmg_batch_blas_t(dtype, op, ca[0] if ca else None, cb[0] if cb else None, _vp(x), _vp(y), _vp(z), C.c_size_t(n), nrhs, C.c_size_t(stride),
+                                 C.c_uint(mask), None), "qmg_batch_blas_t")
+
+
+def batch_multi_caxpy_t(dtype, coeffs, xs, y, n, nrhs, stride, mask):
+    nj = len(xs)
+    cf = np.ascontiguousarray(np.asarray(coeffs, dtype=np.complex128).reshape(nj, nrhs)).view(np.float64)
+    ptrs = (C.c_void_p * nj)(*[x.ptr for x in xs])
+    check(lib().qmg_batch_multi_caxpy_t(dtype, cf.ctypes.data_as(C.POINTER(C.c_double)), ptrs, nj, _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None),
+          "qmg_batch_multi_caxpy_t")
+
+
+def batch_reduce_t(dtype, op, x, y, n, nrhs, stride, mask):
+    out = np.full(2 * nrhs, np.nan)
+    check(lib().qmg_batch_reduce_t(dtype, op, _vp(x), _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), out.ctypes.data_as(C.POINTER(C.c_double)), None),
+          "qmg_batch_reduce_t")
+    return out[0::2] + 1j * out[1::2]
+
+
+def batch_multidot_t(dtype, xs, y, n, nrhs, stride, mask):
+    nj = len(xs)
+    ptrs = (C.c_void_p * nj)(*[x.ptr for x in xs])
+    out = np.full(2 * nrhs * nj, np.nan)
+    check(lib().qmg_batch_multidot_t(dtype, ptrs, nj, _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), out.ctypes.data_as(C.POINTER(C.c_double)), None),
+          "qmg_batch_multidot_t")
+    return (out[0::2] + 1j * out[1::2]).reshape(nrhs, nj)
+
+
+def prolong_batch_t(dtype, nullvecs, nvec, coarse, fine, fdims, cdims, nrhs, cstride, fstride, mask):
+    check(lib().qmg_prolong_batch_t(dtype, _vp(nullvecs), nvec, _vp(coarse), _vp(fine), *fdims, *cdims, nrhs, C.c_size_t(cstride), C.c_size_t(fstride), C.c_uint(mask), None),
+          "qmg_prolong_batch_t")
+
+
+def restrict_batch_t(dtype, nullvecs, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
+    check(lib().qmg_restrict_batch_t(dtype, _vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
+          "qmg_restrict_batch_t")
+
+
+def comm_init_env(world, rank):
+    check(lib().qmg_comm_init_env(world, rank), "qmg_comm_init_env")
+
+
+def comm_all_ok(ok):
+    out = C.c_int(0)
+    check(lib().qmg_comm_all_ok(1 if ok else 0, C.byref(out)), "qmg_comm_all_ok")
+    return bool(out.value)
 
 
 def set_tuning(key, value):

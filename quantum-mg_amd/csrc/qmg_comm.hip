@@ -4,36 +4,43 @@
 // Messages are <= a few KiB: latency-bound; callers fuse every reduction of a Krylov step into ONE
 // buffer and call this once per step.
 //
-// librccl is loaded lazily with dlopen so that single-GPU users (and the CPU build check) do not need
-// it; the calls return QMG_ERR_UNSUPPORTED if it cannot be loaded.
+// Types and enumerators come from <rccl/rccl.h>; the library itself is loaded lazily with dlopen so that
+// single-GPU users (and the CPU build check) do not need librccl at load time; the calls return
+// QMG_ERR_UNSUPPORTED if it cannot be loaded.
+//
+// Rendezvous (qmg_comm_init_env): the 128-byte RCCL id travels the way the launcher already provides --
+//   * QMG_COMM_ID_HEX in the environment (a parent that owns a torch.distributed store broadcasts the id and hands
+//     it to its child this way: bench.py), or
+//   * one TCP exchange on MASTER_ADDR : QMG_COMM_PORT (default MASTER_PORT + 1; MASTER_PORT itself belongs to the
+//     launcher's own store): rank 0 listens and sends the id to each of the world-1 ranks that connect.
+// Every wait is bounded (QMG_COMM_TIMEOUT_S, default 120 s): a missing peer is an error return, never a hang.
+#include <arpa/inet.h>
 #include <dlfcn.h>
+#include <errno.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <rccl/rccl.h>
 
 #include "qmg_common.h"
 
 namespace qmg {
 
-// the handful of RCCL/NCCL declarations used (ABI-stable C API of rccl.h)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccessV = 0 };
-enum { ncclFloat64V = 8 };   // ncclDataType_t: ncclDouble
-enum { ncclSumV = 0 };       // ncclRedOp_t
-
-typedef int (*fn_get_unique_id)(ncclUniqueId*);
-typedef int (*fn_comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int);
-typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
-typedef int (*fn_comm_destroy)(ncclComm_t);
-typedef const char* (*fn_get_error_string)(int);
-
 struct Rccl {
   void* handle = nullptr;
-  fn_get_unique_id get_unique_id = nullptr;
-  fn_comm_init_rank comm_init_rank = nullptr;
-  fn_all_reduce all_reduce = nullptr;
-  fn_comm_destroy comm_destroy = nullptr;
-  fn_get_error_string get_error_string = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) get_error_string = nullptr;
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool force = false;
@@ -42,15 +49,106 @@ struct Rccl {
     handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!handle) handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!handle) return false;
-    get_unique_id = (fn_get_unique_id)dlsym(handle, "ncclGetUniqueId");
-    comm_init_rank = (fn_comm_init_rank)dlsym(handle, "ncclCommInitRank");
-    all_reduce = (fn_all_reduce)dlsym(handle, "ncclAllReduce");
-    comm_destroy = (fn_comm_destroy)dlsym(handle, "ncclCommDestroy");
-    get_error_string = (fn_get_error_string)dlsym(handle, "ncclGetErrorString");
+    get_unique_id = (decltype(get_unique_id))dlsym(handle, "ncclGetUniqueId");
+    comm_init_rank = (decltype(comm_init_rank))dlsym(handle, "ncclCommInitRank");
+    all_reduce = (decltype(all_reduce))dlsym(handle, "ncclAllReduce");
+    comm_destroy = (decltype(comm_destroy))dlsym(handle, "ncclCommDestroy");
+    get_error_string = (decltype(get_error_string))dlsym(handle, "ncclGetErrorString");
     return get_unique_id && comm_init_rank && all_reduce && comm_destroy;
   }
 };
 static Rccl g_rccl;
+
+static_assert(sizeof(ncclUniqueId) == 128, "the C-ABI ships the RCCL id as 128 bytes");
+
+static double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static int timeout_s() { const char* t = getenv("QMG_COMM_TIMEOUT_S"); const int v = t ? atoi(t) : 120; return v > 0 ? v : 120; }
+
+static bool send_all(int fd, const void* buf, size_t n) {
+  const char* p = (const char*)buf;
+  while (n) { const ssize_t w = send(fd, p, n, MSG_NOSIGNAL); if (w <= 0) { if (errno == EINTR) continue; return false; } p += w; n -= (size_t)w; }
+  return true;
+}
+static bool recv_all(int fd, void* buf, size_t n, double deadline) {
+  char* p = (char*)buf;
+  while (n) {
+    pollfd pf = {fd, POLLIN, 0};
+    const double left = deadline - now_s();
+    if (left <= 0 || poll(&pf, 1, (int)(left * 1000) + 1) <= 0) return false;
+    const ssize_t r = recv(fd, p, n, 0);
+    if (r <= 0) { if (r < 0 && errno == EINTR) continue; return false; }
+    p += r; n -= (size_t)r;
+  }
+  return true;
+}
+
+// "QMGID" + world + rank: a stray connection (or a rank of another launch) is told apart from a peer
+struct Hello { char magic[8]; int world, rank; };
+
+static int tcp_exchange_id(ncclUniqueId* id, int world, int rank) {
+  const char* addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+  int port = getenv("QMG_COMM_PORT") ? atoi(getenv("QMG_COMM_PORT")) : (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 1 : 29511);
+  const double deadline = now_s() + timeout_s();
+  char portstr[16];
+  snprintf(portstr, sizeof portstr, "%d", port);
+  if (rank == 0) {
+    const int ls = socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) return QMG_ERR_INVALID;
+    int one = 1;
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((uint16_t)port);
+    if (bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || listen(ls, world) != 0) { close(ls); set_hip_error(hipErrorUnknown, "qmg_comm: cannot listen on QMG_COMM_PORT"); return QMG_ERR_INVALID; }
+    int served = 0;
+    while (served < world - 1) {
+      pollfd pf = {ls, POLLIN, 0};
+      const double left = deadline - now_s();
+      if (left <= 0 || poll(&pf, 1, (int)(left * 1000) + 1) <= 0) { close(ls); set_hip_error(hipErrorUnknown, "qmg_comm: timed out waiting for ranks"); return QMG_ERR_INVALID; }
+      const int fd = accept(ls, nullptr, nullptr);
+      if (fd < 0) continue;
+      Hello h;
+      if (recv_all(fd, &h, sizeof h, now_s() + 5.0) && !memcmp(h.magic, "QMGID\0\0", 8) && h.world == world && h.rank > 0 && h.rank < world && send_all(fd, id, sizeof *id)) served++;
+      close(fd);
+    }
+    close(ls);
+    return QMG_SUCCESS;
+  }
+  addrinfo hints, *res = nullptr;
+  memset(&hints, 0, sizeof hints);
+  hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+  if (getaddrinfo(addr, portstr, &hints, &res) != 0 || !res) { set_hip_error(hipErrorUnknown, "qmg_comm: cannot resolve MASTER_ADDR"); return QMG_ERR_INVALID; }
+  int rc = QMG_ERR_INVALID;
+  while (now_s() < deadline) {   // rank 0 may not be listening yet: retry the connect, bounded
+    const int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) break;
+    if (connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+      Hello h;
+      memset(&h, 0, sizeof h);
+      memcpy(h.magic, "QMGID", 5); h.world = world; h.rank = rank;
+      if (send_all(fd, &h, sizeof h) && recv_all(fd, id, sizeof *id, deadline)) { close(fd); rc = QMG_SUCCESS; break; }
+    }
+    close(fd);
+    usleep(50 * 1000);
+  }
+  freeaddrinfo(res);
+  if (rc) set_hip_error(hipErrorUnknown, "qmg_comm: timed out fetching the RCCL id from rank 0");
+  return rc;
+}
+
+static bool hex_to_id(const char* hex, ncclUniqueId* id) {
+  if (strlen(hex) != 2 * sizeof(ncclUniqueId)) return false;
+  for (size_t i = 0; i < sizeof(ncclUniqueId); i++) {
+    unsigned v;
+    if (sscanf(hex + 2 * i, "%2x", &v) != 1) return false;
+    id->internal[i] = (char)v;
+  }
+  return true;
+}
 
 }  // namespace qmg
 
@@ -58,12 +156,12 @@ using namespace qmg;
 
 extern "C" {
 
-// Rank 0 calls this and ships the 128 bytes to the other ranks by any host channel (file, env, torch.distributed).
+// Rank 0 calls this and ships the 128 bytes to the other ranks by any host channel (env, TCP, torch.distributed).
 int qmg_comm_get_unique_id(void* id128) {
   if (!id128) return QMG_ERR_INVALID;
   if (!g_rccl.load()) return QMG_ERR_UNSUPPORTED;
   ncclUniqueId id;
-  if (g_rccl.get_unique_id(&id) != ncclSuccessV) return QMG_ERR_HIP;
+  if (g_rccl.get_unique_id(&id) != ncclSuccess) return QMG_ERR_HIP;
   memcpy(id128, &id, sizeof(id));
   return QMG_SUCCESS;
 }
@@ -78,8 +176,34 @@ int qmg_comm_init(const void* id128, int world, int rank) {
   if (!g_rccl.load()) return QMG_ERR_UNSUPPORTED;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  if (g_rccl.comm_init_rank(&g_rccl.comm, world, id, rank) != ncclSuccessV) return QMG_ERR_HIP;
+  if (g_rccl.comm_init_rank(&g_rccl.comm, world, id, rank) != ncclSuccess) return QMG_ERR_HIP;
   return QMG_SUCCESS;
+}
+
+// The TCP leg of the rendezvous on its own: rank 0's 128 bytes reach every other rank (bounded waits; no GPU involved,
+// so the host logic is testable with plain processes: tests/test_distributed_cpu.py).
+int qmg_comm_rendezvous(void* blob128, int world, int rank) {
+  if (!blob128 || world < 1 || rank < 0 || rank >= world) return QMG_ERR_INVALID;
+  if (world == 1) return QMG_SUCCESS;
+  return tcp_exchange_id(reinterpret_cast<ncclUniqueId*>(blob128), world, rank);
+}
+
+// qmg_comm_init with the id obtained through the launcher's rendezvous (see the header of this file).
+int qmg_comm_init_env(int world, int rank) {
+  if (world < 1 || rank < 0 || rank >= world) return QMG_ERR_INVALID;
+  const bool force = getenv("QMG_COMM_FORCE_RCCL") != nullptr;
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  if (world > 1 || force) {
+    if (!g_rccl.load()) return QMG_ERR_UNSUPPORTED;
+    const char* hex = getenv("QMG_COMM_ID_HEX");
+    if (hex) { if (!hex_to_id(hex, &id)) return QMG_ERR_INVALID; }
+    else {
+      if (rank == 0 && g_rccl.get_unique_id(&id) != ncclSuccess) return QMG_ERR_HIP;
+      if (world > 1) { const int rc = tcp_exchange_id(&id, world, rank); if (rc) return rc; }
+    }
+  }
+  return qmg_comm_init(&id, world, rank);
 }
 
 int qmg_comm_world(int* world, int* rank) {
@@ -93,7 +217,25 @@ int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream) {
   if (!buf_dev && n) return QMG_ERR_INVALID;
   if ((g_rccl.world == 1 && !g_rccl.force) || n == 0) return QMG_SUCCESS;
   if (!g_rccl.comm) return QMG_ERR_INVALID;
-  if (g_rccl.all_reduce(buf_dev, buf_dev, n, ncclFloat64V, ncclSumV, g_rccl.comm, as_stream(stream)) != ncclSuccessV) return QMG_ERR_HIP;
+  if (g_rccl.all_reduce(buf_dev, buf_dev, n, ncclDouble, ncclSum, g_rccl.comm, as_stream(stream)) != ncclSuccess) return QMG_ERR_HIP;
+  return QMG_SUCCESS;
+}
+
+// *all_ok = 1 iff every rank passed ok != 0.  One all-reduce of one double: a rank that failed locally can tell the
+// others BEFORE they enter the next data collective, so all ranks leave together instead of one leaving the rest blocked.
+int qmg_comm_all_ok(int ok, int* all_ok) {
+  if (!all_ok) return QMG_ERR_INVALID;
+  *all_ok = ok ? 1 : 0;
+  if (g_rccl.world == 1 && !g_rccl.force) return QMG_SUCCESS;
+  if (!g_rccl.comm) return QMG_ERR_INVALID;
+  static double* flag = nullptr;   // one rank = one device = one buffer
+  if (!flag) QMG_HIP_CHECK(hipMalloc((void**)&flag, sizeof(double)));
+  const double bad = ok ? 0.0 : 1.0;
+  double total = 0.0;
+  QMG_HIP_CHECK(hipMemcpy(flag, &bad, sizeof(double), hipMemcpyHostToDevice));
+  if (g_rccl.all_reduce(flag, flag, 1, ncclDouble, ncclSum, g_rccl.comm, nullptr) != ncclSuccess) return QMG_ERR_HIP;
+  QMG_HIP_CHECK(hipMemcpy(&total, flag, sizeof(double), hipMemcpyDeviceToHost));
+  *all_ok = (total == 0.0) ? 1 : 0;
   return QMG_SUCCESS;
 }
 

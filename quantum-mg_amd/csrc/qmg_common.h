@@ -96,6 +96,79 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// ---------------- storage precision (qmg_dtype) ----------------
+// Vectors and matrices are STORED as complex<double> (QMG_C64) or complex<float> (QMG_C32).  Except in the fine-stencil
+// kernel A (which computes in the storage type), arithmetic and every reduction accumulate in fp64 registers: an element
+// is widened when loaded and rounded once when stored, so an fp32 kernel moves half the bytes of its fp64 twin and
+// differs from it by one rounding per stored element.
+template <typename T> struct CStore;
+template <> struct CStore<double> { typedef double2 type; };
+template <> struct CStore<float> { typedef float2 type; };
+
+template <typename T>
+__device__ __forceinline__ cplx ldc(const void* base, long i) {
+  if (sizeof(T) == 8) return reinterpret_cast<const cplx*>(base)[i];
+  const float2 v = reinterpret_cast<const float2*>(base)[i];
+  return make_double2((double)v.x, (double)v.y);
+}
+// read-once stream: bypass-on-evict hint
+template <typename T>
+__device__ __forceinline__ cplx ldc_nt(const void* base, long i) {
+  if (sizeof(T) == 8) {
+    const cplx* p = reinterpret_cast<const cplx*>(base) + i;
+    cplx v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  }
+  const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long*>(base) + i);
+  return make_double2((double)__int_as_float((int)(raw & 0xFFFFFFFFll)), (double)__int_as_float((int)(raw >> 32)));
+}
+template <typename T>
+__device__ __forceinline__ void stc(void* base, long i, cplx v) {
+  if (sizeof(T) == 8) reinterpret_cast<cplx*>(base)[i] = v;
+  else reinterpret_cast<float2*>(base)[i] = make_float2((float)v.x, (float)v.y);
+}
+// W consecutive elements starting at element i*W: one 16-byte access per lane for (double, W = 1) and (float, W = 2).
+// The (float, 2) form needs base 16-byte aligned (the launchers check and fall back to W = 1).
+template <typename T, int W>
+__device__ __forceinline__ void ldc_pack(const void* base, long ipack, cplx (&v)[W]) {
+  if (sizeof(T) == 4 && W == 2) {
+    const float4 r = reinterpret_cast<const float4*>(base)[ipack];
+    v[0] = make_double2((double)r.x, (double)r.y);
+    v[W - 1] = make_double2((double)r.z, (double)r.w);
+  } else {
+#pragma unroll
+    for (int w = 0; w < W; w++) v[w] = ldc<T>(base, ipack * W + w);
+  }
+}
+template <typename T, int W>
+__device__ __forceinline__ void stc_pack(void* base, long ipack, const cplx (&v)[W]) {
+  if (sizeof(T) == 4 && W == 2) {
+    reinterpret_cast<float4*>(base)[ipack] = make_float4((float)v[0].x, (float)v[0].y, (float)v[W - 1].x, (float)v[W - 1].y);
+  } else {
+#pragma unroll
+    for (int w = 0; w < W; w++) stc<T>(base, ipack * W + w, v[w]);
+  }
+}
+inline size_t dtype_size(int dtype) { return dtype == QMG_C32 ? 8 : 16; }
+inline bool valid_dtype(int dtype) { return dtype == QMG_C64 || dtype == QMG_C32; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------- lock-step batches: the active systems of a call ----------------
+constexpr int BATCH_MAX = 16;
+struct BatchIdx { int n; unsigned char id[BATCH_MAX]; };
+inline BatchIdx expand_mask(unsigned mask, int nrhs) {
+  BatchIdx b;
+  b.n = 0;
+  for (int k = 0; k < nrhs && k < BATCH_MAX; k++)
+    if ((mask >> k) & 1u) b.id[b.n++] = (unsigned char)k;
+  for (int k = b.n; k < BATCH_MAX; k++) b.id[k] = 0;
+  return b;
+}
+
+extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
+
 // Memory-bound 1-D launches.  One 16-byte element per thread up to 2^18 blocks, grid-stride beyond: on this part a
 // streaming copy reaches 6.2 TB/s at 262 144 blocks but only 5.4 TB/s at 8 192 (profiles/r01_membw_ceiling.txt).
 inline unsigned grid_1d(size_t work_items, int per_block = BLOCK) {

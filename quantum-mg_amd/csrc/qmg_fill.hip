@@ -234,11 +234,30 @@ __global__ __launch_bounds__(BLOCK) void k_c64_to_c32(float2* __restrict__ dst, 
   }
 }
 
+// element-wise copy between storage precisions (round to nearest / widen)
+template <typename TD, typename TS>
+__global__ __launch_bounds__(BLOCK) void k_convert(void* __restrict__ dst, const void* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) stc<TD>(dst, i, ldc<TS>(src, i));
+}
+
 }  // namespace qmg
 
 using namespace qmg;
 
 extern "C" {
+
+int qmg_convert(void* dst, int dst_dtype, const void* src, int src_dtype, size_t n, void* stream) {
+  if (!valid_dtype(dst_dtype) || !valid_dtype(src_dtype) || ((!dst || !src) && n)) return QMG_ERR_INVALID;
+  if (n == 0) return QMG_SUCCESS;
+  hipStream_t st = as_stream(stream);
+  const unsigned g = grid_1d(n);
+  if (dst_dtype == QMG_C64 && src_dtype == QMG_C64) k_convert<double, double><<<g, BLOCK, 0, st>>>(dst, src, (long)n);
+  else if (dst_dtype == QMG_C32 && src_dtype == QMG_C64) k_convert<float, double><<<g, BLOCK, 0, st>>>(dst, src, (long)n);
+  else if (dst_dtype == QMG_C64 && src_dtype == QMG_C32) k_convert<double, float><<<g, BLOCK, 0, st>>>(dst, src, (long)n);
+  else k_convert<float, float><<<g, BLOCK, 0, st>>>(dst, src, (long)n);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
 
 int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, int Ly, void* stream) {
   if (!lhs || !rhs || dof < 1 || !valid_lattice(Lx, Ly)) return QMG_ERR_INVALID;

@@ -33,8 +33,8 @@ namespace qmg {
 struct StencilArgs {
   const cplx* clover;
   const cplx* hopping;
-  cplx* lhs;
-  const cplx* rhs;
+  void* lhs;         // vectors: complex<double>, or complex<float> when vec32
+  const void* rhs;
   int hr;            // Lx / 2: sites per half row
   int Ly;
   long half_vol;     // sites per parity
@@ -48,11 +48,26 @@ struct StencilArgs {
   double shift[2], eo_shift[2], dof_shift[2];
   unsigned char ridx[16];   // masked batches (qmg_stencil_apply_batch): right-hand side processed as column k; else unused
   int use_idx;       // 0: column k is right-hand side k
-  int mat32;         // 1: clover / hopping point to complex<float> arrays (qmg_stencil_apply_mat32; kernels B and C only)
-  int ablate;        // diagnostic builds only (tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
+  int mat32;         // 1: clover / hopping point to complex<float> arrays (kernels B and C: qmg_stencil_apply_mat32, qmg_stencil_apply_t)
+  int vec32;         // 1: lhs / rhs are complex<float> (qmg_stencil_apply_t with QMG_C32: matrices AND vectors fp32)
+#ifdef QMG_DIAGNOSTICS
+  int ablate;        // tools-only build (make DIAG=1; tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
+#endif
 };
 
+// Ablation switches exist only in the tools build (-DQMG_DIAGNOSTICS, `make DIAG=1`, never shipped): in libqmg_hip.so the
+// test is the constant 0 and every ablated path is dead code.
+#ifdef QMG_DIAGNOSTICS
+#define QMG_ABLATE(a, bits) ((a).ablate & (bits))
+#else
+#define QMG_ABLATE(a, bits) 0
+#endif
+
 __device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)(a.use_idx ? (int)a.ridx[k] : k) * a.vec_stride; }
+
+// vector element i of a complex<double> (V32 = false) or complex<float> (V32 = true) array, in fp64 registers
+template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i) { return V32 ? ldc<float>(base, i) : ldc<double>(base, i); }
+template <bool V32> __device__ __forceinline__ void stv(void* base, long i, cplx v) { if (V32) stc<float>(base, i, v); else stc<double>(base, i, v); }
 
 template <bool NT>
 __device__ __forceinline__ cplx ld(const cplx* p) {
@@ -107,11 +122,103 @@ __device__ __forceinline__ void st(cplx* p, cplx v) {
   }
 }
 
-template <int NC, bool NT, bool NTS>
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel A lane layout, either storage precision.  A lane owns CW consecutive column entries of one matrix row, i.e. ONE
+// 16-byte fragment of each matrix and of each vector it needs:
+//     fp64: CW = 1  -- lane (r, c) holds M[r][c] and x[c]                      (nc^2 lanes per site)
+//     fp32: CW = 2  -- lane (r, h) holds M[r][2h..2h+1] and x[2h..2h+1]        (nc^2/2 lanes per site; nc = 1: CW = 1, 8 bytes)
+// so every matrix load of a wavefront is one coalesced 1-KiB segment in BOTH precisions (with 8-byte loads the fp32
+// kernel would issue the same number of load instructions for half the bytes).  For Wilson fp32 (nc = 2) a lane then
+// holds a whole matrix row and the whole site vector: the row sum needs no cross-lane step at all.  The kernel computes
+// in the storage type T (the fine operator is the one place fp32 ARITHMETIC is used: SURVEY 8c states 5e-6 per apply).
+template <typename T, int NC>
+struct KA {
+  typedef typename CStore<T>::type ct;
+  static constexpr int CW = (sizeof(T) == 4 && NC % 2 == 0) ? 2 : 1;
+  static constexpr int LPR = NC / CW;          // lanes per matrix row
+  static constexpr int E = NC * LPR;           // lanes per site
+  struct Frag { ct v[CW]; };
+};
+
+template <typename T> __device__ __forceinline__ typename CStore<T>::type czero() { typename CStore<T>::type z; z.x = (T)0; z.y = (T)0; return z; }
+template <typename CT> __device__ __forceinline__ void cmac_t(CT& acc, CT a, CT b) {
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ float lane_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float lane_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// fragment `idx` (in units of CW elements) of a T-typed array
+template <typename T, int NC, bool NT>
+__device__ __forceinline__ typename KA<T, NC>::Frag ld_frag(const void* base, long idx) {
+  typename KA<T, NC>::Frag f;
+  if constexpr (sizeof(T) == 8) {
+    f.v[0] = ld<NT>(reinterpret_cast<const cplx*>(base) + idx);
+  } else if constexpr (KA<T, NC>::CW == 2) {
+    const v4f* p = reinterpret_cast<const v4f*>(base) + idx;
+    const v4f r = NT ? __builtin_nontemporal_load(p) : *p;
+    f.v[0].x = r.x; f.v[0].y = r.y; f.v[1].x = r.z; f.v[1].y = r.w;
+  } else {
+    const long long* p = reinterpret_cast<const long long*>(base) + idx;
+    const long long raw = NT ? __builtin_nontemporal_load(p) : *p;
+    f.v[0].x = __int_as_float((int)(raw & 0xFFFFFFFFll));
+    f.v[0].y = __int_as_float((int)(raw >> 32));
+  }
+  return f;
+}
+template <typename T, int NC> __device__ __forceinline__ typename KA<T, NC>::Frag zero_frag() {
+  typename KA<T, NC>::Frag f;
+#pragma unroll
+  for (int w = 0; w < KA<T, NC>::CW; w++) f.v[w] = czero<T>();
+  return f;
+}
+template <typename T, int NC>
+__device__ __forceinline__ void fmac(typename CStore<T>::type& acc, const typename KA<T, NC>::Frag& m, const typename KA<T, NC>::Frag& x) {
+#pragma unroll
+  for (int w = 0; w < KA<T, NC>::CW; w++) cmac_t(acc, m.v[w], x.v[w]);
+}
+// sum over the LPR lanes of a matrix row (adjacent lanes)
+template <typename T, int NC> __device__ __forceinline__ void row_sum(typename CStore<T>::type& acc) {
+  if (KA<T, NC>::LPR >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
+  if (KA<T, NC>::LPR >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
+}
+// the shift coefficient on the diagonal, as a fragment: shift +- eo_shift +- dof_shift at column r (stencil_2d.h:890-908)
+template <typename T, int NC>
+__device__ __forceinline__ typename KA<T, NC>::Frag shift_frag(const StencilArgs& a, bool do_shift, int p, int r, int c0) {
+  typename KA<T, NC>::Frag sh = zero_frag<T, NC>();
+  if (do_shift) {
+    const double sg = p ? -1.0 : 1.0;
+    const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+#pragma unroll
+    for (int w = 0; w < KA<T, NC>::CW; w++)
+      if (c0 + w == r) {
+        sh.v[w].x = (T)(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0]);
+        sh.v[w].y = (T)(a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+      }
+  }
+  return sh;
+}
+template <typename T, bool NTS>
+__device__ __forceinline__ void st_elem(void* base, long i, typename CStore<T>::type v) {
+  typedef typename CStore<T>::type ct;
+  ct* p = reinterpret_cast<ct*>(base) + i;
+  if (NTS) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); }
+  else *p = v;
+}
+
+template <typename T, int NC, bool NT, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
-  constexpr int E = NC * NC;
+  typedef KA<T, NC> K;
+  typedef typename K::ct ct;
+  typedef typename K::Frag Frag;
+  constexpr int E = K::E, CW = K::CW, FPS = NC * NC / CW, VPS = NC / CW;   // fragments per site: matrix, vector
   const int e = threadIdx.x % E;
-  const int r = e / NC, c = e % NC;
+  const int r = e / K::LPR, c0 = (e % K::LPR) * CW;
+  const int vf = e % K::LPR;            // this lane's vector fragment within a site
   const int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
   if (j >= a.hr) return;   // whole site groups leave together (E divides BLOCK)
 
@@ -136,47 +243,37 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
     nb[2] = opp + (long)y * a.hr + jm;
     nb[3] = opp + (long)ym * a.hr + j;
 
-    // Stencil matrices: one coalesced 16-byte element per lane per matrix; kept in registers
+    // Stencil matrices: one coalesced 16-byte fragment per lane per matrix; kept in registers
     // across all right-hand sides.
-    cplx m[5];
-    m[4] = do_clover ? ld<NT>(a.clover + site * E + e) : cmake(0.0, 0.0);
+    Frag m[5];
+    m[4] = do_clover ? ld_frag<T, NC, NT>(a.clover, site * FPS + e) : zero_frag<T, NC>();
 #pragma unroll
     for (int d = 0; d < 4; d++)
-      m[d] = ((hop_mask >> d) & 1u) ? ld<NT>(a.hopping + (long)d * a.size_cm + site * E + e) : cmake(0.0, 0.0);
-
-    // shift coefficient on the diagonal: shift +- eo_shift +- dof_shift (stencil_2d.h:890-908)
-    cplx sh = cmake(0.0, 0.0);
-    if (do_shift && r == c) {
-      const double sg = p ? -1.0 : 1.0;
-      const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
-      sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
-                 a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
-    }
+      m[d] = ((hop_mask >> d) & 1u) ? ld_frag<T, NC, NT>(a.hopping, ((long)d * a.size_cm) / CW + site * FPS + e) : zero_frag<T, NC>();
+    const Frag sh = shift_frag<T, NC>(a, do_shift, p, r, c0);
     const bool need_own = do_clover || do_shift;
 
     for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + rhs_offset(a, k);
-      cplx* out = a.lhs + rhs_offset(a, k);
-      cplx xv[5];
+      const ct* x = reinterpret_cast<const ct*>(a.rhs) + rhs_offset(a, k);
+      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset(a, k);
+      Frag xv[5];
 #pragma unroll
       for (int d = 0; d < 4; d++)
-        xv[d] = ((hop_mask >> d) & 1u) ? x[((a.ablate & 1) ? site : nb[d]) * NC + c] : cmake(0.0, 0.0);
-      xv[4] = need_own ? x[site * NC + c] : cmake(0.0, 0.0);
-      if (a.ablate & 4) { xv[0] = xv[1] = xv[2] = xv[3] = xv[4] = cmake(1.0 + c, 0.5); }
+        xv[d] = ((hop_mask >> d) & 1u) ? ld_frag<T, NC, false>(x, (QMG_ABLATE(a, 1) ? site : nb[d]) * VPS + vf) : zero_frag<T, NC>();
+      xv[4] = need_own ? ld_frag<T, NC, false>(x, site * VPS + vf) : zero_frag<T, NC>();
+      if (QMG_ABLATE(a, 4)) { for (int d = 0; d < 5; d++) for (int w = 0; w < CW; w++) { xv[d].v[w].x = (T)(1.0 + c0 + w); xv[d].v[w].y = (T)0.5; } }
 
-      cplx acc = cmake(0.0, 0.0);
-      cmac(acc, m[4], xv[4]);                       // clover first, as the reference does
+      ct acc = czero<T>();
+      fmac<T, NC>(acc, m[4], xv[4]);                       // clover first, as the reference does
 #pragma unroll
-      for (int d = 0; d < 4; d++) cmac(acc, m[d], xv[d]);
-      cmac(acc, sh, xv[4]);
+      for (int d = 0; d < 4; d++) fmac<T, NC>(acc, m[d], xv[d]);
+      fmac<T, NC>(acc, sh, xv[4]);
+      row_sum<T, NC>(acc);
 
-      if (NC >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
-      if (NC >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
-
-      if ((a.ablate & 2) && acc.x != 1.2345e300) continue;
-      if (c == 0) {
-        if (!do_zero) acc = cadd(out[site * NC + r], acc);
-        st<NTS>(out + site * NC + r, acc);
+      if (QMG_ABLATE(a, 2) && acc.x != (T)1.2345e30) continue;
+      if (c0 == 0) {
+        if (!do_zero) { const ct o = out[site * NC + r]; acc.x += o.x; acc.y += o.y; }
+        st_elem<T, NTS>(out, site * NC + r, acc);
       }
     }
   }
@@ -188,35 +285,33 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
 // mutual x-neighbours (x = 2j and 2j+1, in an order set by y&1) and the rows share their
 // y-neighbours, so the right-hand side is loaded into registers once for all 2*ROWS outputs:
 // 2(ROWS+2) column values + 2 ROWS side values instead of 10 ROWS.  More importantly each
-// wavefront now streams 2*ROWS*5 matrix elements per lane (ROWS=2: 32 KiB of loads in flight per
+// wavefront now streams 2*ROWS*5 matrix fragments per lane (ROWS=2: 32 KiB of loads in flight per
 // wave), which takes the launch out of the "a million 6-KiB waves" regime where wave dispatch,
 // not HBM, sets the pace (tools/membw2.hip: 5.3 TB/s at 1M blocks vs 6.4-6.7 TB/s at 64K).
 // ------------------------------------------------------------------------------------------
-template <int NC, int ROWS, bool NT, bool NTS>
+template <typename T, int NC, int ROWS, bool NT, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
-  constexpr int E = NC * NC;
+  typedef KA<T, NC> K;
+  typedef typename K::ct ct;
+  typedef typename K::Frag Frag;
+  constexpr int E = K::E, CW = K::CW, FPS = NC * NC / CW, VPS = NC / CW;
   const int e = threadIdx.x % E;
-  const int r = e / NC, c = e % NC;
+  const int r = e / K::LPR, c0 = (e % K::LPR) * CW;
+  const int vf = e % K::LPR;
   const int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
   if (j >= a.hr) return;
   const int ngroups = a.Ly / ROWS;
 
   bool do_clover[2], do_shift[2], do_zero[2];
   unsigned hop_mask[2];
-  cplx sh[2];
+  Frag sh[2];
 #pragma unroll
   for (int p = 0; p < 2; p++) {
     do_clover[p] = a.clover && ((a.pieces >> p) & 1u);
     hop_mask[p] = a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u;
     do_shift[p] = (a.pieces >> (10 + p)) & 1u;
     do_zero[p] = (a.pieces >> (12 + p)) & 1u;
-    sh[p] = cmake(0.0, 0.0);
-    if (do_shift[p] && r == c) {
-      const double sg = p ? -1.0 : 1.0;
-      const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
-      sh[p] = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0],
-                    a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
-    }
+    sh[p] = shift_frag<T, NC>(a, do_shift[p], p, r, c0);
   }
   const bool any_hop = (hop_mask[0] | hop_mask[1]) != 0u;
   int jl = j - 1; if (jl < 0) jl = a.hr - 1;
@@ -225,27 +320,27 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
   for (int grp = blockIdx.y; grp < ngroups; grp += gridDim.y) {
     const int y0 = grp * ROWS;
 
-    // ---- stencil matrices: 2*ROWS*5 coalesced 16-byte elements per lane
-    cplx m[ROWS][2][5];
+    // ---- stencil matrices: 2*ROWS*5 coalesced 16-byte fragments per lane
+    Frag m[ROWS][2][5];
 #pragma unroll
     for (int rr = 0; rr < ROWS; rr++)
 #pragma unroll
       for (int p = 0; p < 2; p++) {
         const long site = (long)p * a.half_vol + (long)(y0 + rr) * a.hr + j;
-        m[rr][p][4] = do_clover[p] ? ld<NT>(a.clover + site * E + e) : cmake(0.0, 0.0);
+        m[rr][p][4] = do_clover[p] ? ld_frag<T, NC, NT>(a.clover, site * FPS + e) : zero_frag<T, NC>();
 #pragma unroll
         for (int d = 0; d < 4; d++)
-          m[rr][p][d] = ((hop_mask[p] >> d) & 1u) ? ld<NT>(a.hopping + (long)d * a.size_cm + site * E + e) : cmake(0.0, 0.0);
+          m[rr][p][d] = ((hop_mask[p] >> d) & 1u) ? ld_frag<T, NC, NT>(a.hopping, ((long)d * a.size_cm) / CW + site * FPS + e) : zero_frag<T, NC>();
       }
 
     for (int k = 0; k < a.nrhs; k++) {
-      const cplx* x = a.rhs + rhs_offset(a, k);
-      cplx* out = a.lhs + rhs_offset(a, k);
-      const cplx* xe = x;                       // even half
-      const cplx* xo = x + a.half_vol * NC;     // odd half
+      const ct* x = reinterpret_cast<const ct*>(a.rhs) + rhs_offset(a, k);
+      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset(a, k);
+      const ct* xe = x;                       // even half
+      const ct* xo = x + a.half_vol * NC;     // odd half
 
       // ---- right-hand side: rows y0-1 .. y0+ROWS at column j, both parities
-      cplx Ec[ROWS + 2], Oc[ROWS + 2];
+      Frag Ec[ROWS + 2], Oc[ROWS + 2];
 #pragma unroll
       for (int t = 0; t < ROWS + 2; t++) {
         int yy = y0 - 1 + t;
@@ -253,23 +348,23 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
         if (yy >= a.Ly) yy -= a.Ly;
         const bool edge = (t == 0 || t == ROWS + 1);
         if (!edge || any_hop) {
-          Ec[t] = xe[((long)yy * a.hr + j) * NC + c];
-          Oc[t] = xo[((long)yy * a.hr + j) * NC + c];
+          Ec[t] = ld_frag<T, NC, false>(xe, ((long)yy * a.hr + j) * VPS + vf);
+          Oc[t] = ld_frag<T, NC, false>(xo, ((long)yy * a.hr + j) * VPS + vf);
         } else {
-          Ec[t] = Oc[t] = cmake(0.0, 0.0);
+          Ec[t] = Oc[t] = zero_frag<T, NC>();
         }
       }
       // ---- and the one x-neighbour per row that is not the partner site
-      cplx Es[ROWS], Os[ROWS];
+      Frag Es[ROWS], Os[ROWS];
 #pragma unroll
       for (int rr = 0; rr < ROWS; rr++) {
         const int y = y0 + rr;
         const int se = y & 1;                    // even site: x = 2j + se ; odd site: x = 2j + 1 - se
         if (any_hop) {
-          Os[rr] = xo[((long)y * a.hr + (se ? jr : jl)) * NC + c];
-          Es[rr] = xe[((long)y * a.hr + (se ? jl : jr)) * NC + c];
+          Os[rr] = ld_frag<T, NC, false>(xo, ((long)y * a.hr + (se ? jr : jl)) * VPS + vf);
+          Es[rr] = ld_frag<T, NC, false>(xe, ((long)y * a.hr + (se ? jl : jr)) * VPS + vf);
         } else {
-          Os[rr] = Es[rr] = cmake(0.0, 0.0);
+          Os[rr] = Es[rr] = zero_frag<T, NC>();
         }
       }
 
@@ -281,29 +376,28 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
         for (int p = 0; p < 2; p++) {
           // neighbours of the parity-p site (y, j); s = (y + p) & 1
           const int s = p ? (1 - se) : se;
-          const cplx own = p ? Oc[rr + 1] : Ec[rr + 1];
-          const cplx partner = p ? Ec[rr + 1] : Oc[rr + 1];     // opposite parity, same (y, j)
-          const cplx side = p ? Es[rr] : Os[rr];                // opposite parity, (y, j + (s ? +1 : -1))
-          cplx xv[4];
+          const Frag own = p ? Oc[rr + 1] : Ec[rr + 1];
+          const Frag partner = p ? Ec[rr + 1] : Oc[rr + 1];     // opposite parity, same (y, j)
+          const Frag side = p ? Es[rr] : Os[rr];                // opposite parity, (y, j + (s ? +1 : -1))
+          Frag xv[4];
           xv[0] = s ? side : partner;                           // +x: (y, j + s)
           xv[2] = s ? partner : side;                           // -x: (y, j + s - 1)
           xv[1] = p ? Ec[rr + 2] : Oc[rr + 2];                  // +y
           xv[3] = p ? Ec[rr] : Oc[rr];                          // -y
           // values this parity does not ask for may be uninitialised memory: never let them into the sum
-          const cplx zero = cmake(0.0, 0.0);
-          const cplx own_u = (do_clover[p] || do_shift[p]) ? own : zero;
-          cplx acc = zero;
-          cmac(acc, m[rr][p][4], own_u);
+          const Frag zero = zero_frag<T, NC>();
+          const Frag own_u = (do_clover[p] || do_shift[p]) ? own : zero;
+          ct acc = czero<T>();
+          fmac<T, NC>(acc, m[rr][p][4], own_u);
 #pragma unroll
-          for (int d = 0; d < 4; d++) cmac(acc, m[rr][p][d], ((hop_mask[p] >> d) & 1u) ? xv[d] : zero);
-          cmac(acc, sh[p], own_u);
-          if (NC >= 2) { acc.x += lane_xor1(acc.x); acc.y += lane_xor1(acc.y); }
-          if (NC >= 4) { acc.x += lane_xor2(acc.x); acc.y += lane_xor2(acc.y); }
+          for (int d = 0; d < 4; d++) fmac<T, NC>(acc, m[rr][p][d], ((hop_mask[p] >> d) & 1u) ? xv[d] : zero);
+          fmac<T, NC>(acc, sh[p], own_u);
+          row_sum<T, NC>(acc);
           const bool touch = do_clover[p] || hop_mask[p] || do_shift[p] || do_zero[p];
-          if (c == 0 && touch) {
+          if (c0 == 0 && touch) {
             const long o = ((long)p * a.half_vol + (long)y * a.hr + j) * NC + r;
-            if (!do_zero[p]) acc = cadd(out[o], acc);
-            st<NTS>(out + o, acc);
+            if (!do_zero[p]) { const ct prev = out[o]; acc.x += prev.x; acc.y += prev.y; }
+            st_elem<T, NTS>(out, o, acc);
           }
         }
       }
@@ -335,7 +429,7 @@ constexpr int GEN_MAX_PER_THREAD = 12;   // register-staged matrix elements per 
 // KR = right-hand sides per pass: the matrix tile parked in LDS is used for KR vectors (KR accumulators per thread), so a
 // batch reads the matrices once per KR systems for ANY nc -- the vector-FMA counterpart of kernel C, and the better one
 // where the 16x16 MFMA tile would be mostly padding (nc = 8: 1024^2, 8 rhs 2.0 ms on the matrix cores).
-template <int PT, bool M32, int KR>
+template <int PT, bool M32, int KR, bool V32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* mlds = reinterpret_cast<cplx*>(smem_raw);                    // [S*nc rows][rs]
@@ -395,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
       auto prefetch = [&](int piece) {
         const cplx* mbase = (piece == 4) ? a.clover : a.hopping;                 // (element offsets, so that the same
         long moff = (piece == 4) ? site0 * nc2 : (long)piece * a.size_cm + site0 * nc2;   //  code serves both matrix widths)
-        if ((a.ablate & 16) && (piece == 2 || piece == 3)) {
+        if (QMG_ABLATE(a, 16) && (piece == 2 || piece == 3)) {
           // diagnostic (wrong arithmetic, right access pattern): what the backward hops would cost if they re-read the
           // neighbour's FORWARD link (gamma5-hermitian link compression) instead of streaming their own array
           long nsite0 = (piece == 2) ? opp + (long)y * a.hr + (j0 + s - 1 < 0 ? 0 : j0 + s - 1) : opp + (long)ym * a.hr + j0;
@@ -429,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
           else nbsite = opp + (long)ym * a.hr + j;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[kk] = a.rhs[rhs_offset(a, k0 + kk) + nbsite * nc + cc];
+            if (kk < nk) xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
         }
       };
       if (oi < 5) { cur = order[oi]; prefetch(cur); }
@@ -467,7 +561,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
         while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
         if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
         __syncthreads();
-        if (worker && s_of < nsite && !(a.ablate & 32)) {
+        if (worker && s_of < nsite && !QMG_ABLATE(a, 32)) {
           const cplx* mrow = mlds + (size_t)sr * L.rs;
           const cplx* xs = xlds + s_of * nc;
           for (int cc = c0; cc < c1; cc++) {
@@ -476,7 +570,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
             for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
           }
         }
-        if (a.ablate & 32) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
+        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
         cur = nxt;
       }
 
@@ -488,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
                               a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
 #pragma unroll
         for (int kk = 0; kk < KR; kk++)
-          if (kk < nk) cmac(acc[kk], sh, a.rhs[rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of]);
+          if (kk < nk) cmac(acc[kk], sh, ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of));
       }
       // sum the H slices, one right-hand side at a time through the same LDS buffer
 #pragma unroll
@@ -500,10 +594,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
         if (h == 0 && s_of < nsite) {
           cplx t = red[sr];
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
-          cplx* out = a.lhs + rhs_offset(a, k0 + kk);
-          const long o = (site0 + s_of) * nc + r_of;
-          if (!do_zero) t = cadd(out[o], t);
-          out[o] = t;
+          const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
+          if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
+          stv<V32>(a.lhs, o, t);
         }
       }
     }
@@ -514,7 +607,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 // loads carry two matrix elements, the staging registers and the LDS tile hold raw float pairs (half the registers, half
 // the LDS: twice the resident blocks), and an element is widened to fp64 only when it is multiplied.  PP = staged PAIRS per
 // thread.  Row stride nc + 2 floats-pairs: even (16-B aligned pair stores) and conflict-free for the 8-byte row reads.
-template <int PP, int KR>
+template <int PP, int KR, bool V32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int rs32 = nc + 2;
@@ -594,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           else nbsite = opp + (long)ym * a.hr + j;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[kk] = a.rhs[rhs_offset(a, k0 + kk) + nbsite * nc + cc];
+            if (kk < nk) xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
         }
       };
       if (oi < 5) { cur = order[oi]; prefetch(cur); }
@@ -620,7 +713,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
         while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
         if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
         __syncthreads();
-        if (worker && s_of < nsite && !(a.ablate & 32)) {
+        if (worker && s_of < nsite && !QMG_ABLATE(a, 32)) {
           const float2* mrow = mlds + (size_t)sr * rs32;
           const cplx* xs = xlds + s_of * nc;
           for (int cc = c0; cc < c1; cc++) {
@@ -630,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
             for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
           }
         }
-        if (a.ablate & 32) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
+        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
         cur = nxt;
       }
 
@@ -642,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
                               a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
 #pragma unroll
         for (int kk = 0; kk < KR; kk++)
-          if (kk < nk) cmac(acc[kk], sh, a.rhs[rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of]);
+          if (kk < nk) cmac(acc[kk], sh, ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of));
       }
       // sum the H slices, one right-hand side at a time through the same LDS buffer
 #pragma unroll
@@ -654,10 +747,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
         if (h == 0 && s_of < nsite) {
           cplx t = red[sr];
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
-          cplx* out = a.lhs + rhs_offset(a, k0 + kk);
-          const long o = (site0 + s_of) * nc + r_of;
-          if (!do_zero) t = cadd(out[o], t);
-          out[o] = t;
+          const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
+          if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
+          stv<V32>(a.lhs, o, t);
         }
       }
     }
@@ -697,7 +789,7 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // at 512^2, nc = 24, 16 rhs: the extra f64 adds and the third accumulator cost more than the saved MFMA -- and dropped.)
 // The f64 matrix pipe sustains 48 TFLOP/s on this part (tools/mfma_f64_rate.hip), which at nc = 24 is 2.7 ms of plain
 // MFMA work per 512^2 apply against 2.4 ms of HBM time -- the MFMA count, not the byte count, is what MODE 1 cuts.
-template <int NC, int MODE, bool M32>
+template <int NC, int MODE, bool M32, bool V32>
 __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, const int nk) {
   constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
   constexpr int NACC = 2;
@@ -767,11 +859,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           G[g] = (NC2 % WAVE == 0 || el < NC2) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
         }
       }
-      const cplx* x = a.rhs + koff + nb[pc] * NC;
+      const long xo = koff + nb[pc] * NC;
 #pragma unroll
       for (int q = 0; q < KS; q++) {
         const int c = 4 * q + lq;
-        const cplx xv = (kval && c < NC) ? x[c] : cmake(0.0, 0.0);
+        const cplx xv = (kval && c < NC) ? ldv<V32>(a.rhs, xo + c) : cmake(0.0, 0.0);
         if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
         else B[set][q] = xv;
       }
@@ -858,10 +950,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           if (do_shift) {
             const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
             const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
-            cmac(v, sh, a.rhs[o]);
+            cmac(v, sh, ldv<V32>(a.rhs, o));
           }
-          if (!do_zero) v = cadd(a.lhs[o], v);
-          a.lhs[o] = v;
+          if (!do_zero) v = cadd(ldv<V32>(a.lhs, o), v);
+          stv<V32>(a.lhs, o, v);
         }
       }
     }
@@ -869,7 +961,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 }
 
 static int g_stencil_nt = 3;     // tuning knob: bit0 non-temporal matrix loads, bit1 non-temporal stores (kernel A)
+#ifdef QMG_DIAGNOSTICS
 static int g_stencil_ablate = 0;
+#endif
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
@@ -906,17 +1000,20 @@ using namespace qmg;
 extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!key) return QMG_ERR_INVALID;
   if (!strcmp(key, "stencil_nt")) { g_stencil_nt = value; return QMG_SUCCESS; }
+#ifdef QMG_DIAGNOSTICS
   if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
+#endif
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "xfer_tile")) { g_xfer_tile = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32 = 0);
+                              const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0);
 
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
@@ -953,8 +1050,25 @@ extern "C" int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, con
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1);
 }
 
+// Either storage precision, masked batch semantics.  QMG_C64: qmg_stencil_apply_batch.  QMG_C32: matrices AND vectors are
+// complex<float>; nc in {1,2,4} run kernel A in fp32 arithmetic, every other nc the fp32-tile kernels B32 / B / C with
+// fp32 vector loads and stores around their fp64 accumulation.
+extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                                   int nrhs, size_t vec_stride, unsigned mask, void* stream) {
+  if (dtype == QMG_C64) return qmg_stencil_apply_batch(d, lhs, rhs, pieces, nrhs, vec_stride, mask, stream);
+  if (dtype != QMG_C32) return QMG_ERR_INVALID;
+  if (nrhs < 1 || nrhs > 16) return QMG_ERR_INVALID;
+  unsigned char ridx[16];
+  int n = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
+  if (n == 0) return QMG_SUCCESS;
+  if (n == nrhs) return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 1, 1);
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1, 1);
+}
+
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32) {
+                              const unsigned char* ridx, void* stream, int mat32, int vec32) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -963,8 +1077,10 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   StencilArgs a;
   a.clover = (const cplx*)d->clover;
   a.hopping = (const cplx*)d->hopping;
-  a.lhs = (cplx*)lhs;
-  a.rhs = (const cplx*)rhs;
+  a.lhs = lhs;
+  a.rhs = rhs;
+  a.vec32 = vec32;
+  if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   a.hr = d->Lx / 2;
   a.Ly = d->Ly;
   a.half_vol = (long)a.hr * d->Ly;
@@ -975,7 +1091,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.use_idx = ridx ? 1 : 0;
   a.mat32 = mat32;
   for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
+#ifdef QMG_DIAGNOSTICS
   a.ablate = g_stencil_ablate;
+#endif
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
 
   // which parity halves have any work
@@ -991,43 +1109,47 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   hipStream_t st = as_stream(stream);
 
   if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && g_stencil_pair > 0 && lhs != rhs) {
-    const int E = nc * nc;
+    const int E = (vec32 && nc % 2 == 0) ? nc * nc / 2 : nc * nc;   // lanes per site (KA<T, NC>::E)
     const int rows = (g_stencil_pair >= 4 && d->Ly % 4 == 0) ? 4 : (g_stencil_pair >= 2 && d->Ly % 2 == 0) ? 2 : 1;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
     unsigned gyp = (unsigned)(d->Ly / rows);
     if (gyp > 65535u) gyp = 65535u;
     if (g_stencil_rows > 0 && gyp > (unsigned)g_stencil_rows) gyp = (unsigned)g_stencil_rows;
     dim3 grid(gx, gyp), block(BLOCK);
-#define QMG_PAIR_LAUNCH(NC, ROWS)                                                             \
+#define QMG_PAIR_LAUNCH_T(T, NC, ROWS)                                                        \
     switch (g_stencil_nt & 3) {                                                               \
-      case 0: k_stencil_pair<NC, ROWS, false, false><<<grid, block, 0, st>>>(a); break;       \
-      case 1: k_stencil_pair<NC, ROWS, true, false><<<grid, block, 0, st>>>(a); break;        \
-      case 2: k_stencil_pair<NC, ROWS, false, true><<<grid, block, 0, st>>>(a); break;        \
-      default: k_stencil_pair<NC, ROWS, true, true><<<grid, block, 0, st>>>(a); break;        \
+      case 0: k_stencil_pair<T, NC, ROWS, false, false><<<grid, block, 0, st>>>(a); break;    \
+      case 1: k_stencil_pair<T, NC, ROWS, true, false><<<grid, block, 0, st>>>(a); break;     \
+      case 2: k_stencil_pair<T, NC, ROWS, false, true><<<grid, block, 0, st>>>(a); break;     \
+      default: k_stencil_pair<T, NC, ROWS, true, true><<<grid, block, 0, st>>>(a); break;     \
     }
+#define QMG_PAIR_LAUNCH(NC, ROWS) if (vec32) { QMG_PAIR_LAUNCH_T(float, NC, ROWS) } else { QMG_PAIR_LAUNCH_T(double, NC, ROWS) }
     if (nc == 1) { if (rows == 4) { QMG_PAIR_LAUNCH(1, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(1, 2) } else { QMG_PAIR_LAUNCH(1, 1) } }
     if (nc == 2) { if (rows == 4) { QMG_PAIR_LAUNCH(2, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(2, 2) } else { QMG_PAIR_LAUNCH(2, 1) } }
     if (nc == 4) { if (rows >= 2) { QMG_PAIR_LAUNCH(4, 2) } else { QMG_PAIR_LAUNCH(4, 1) } }
 #undef QMG_PAIR_LAUNCH
+#undef QMG_PAIR_LAUNCH_T
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }
 
   if (nc == 1 || nc == 2 || nc == 4) {
-    const int E = nc * nc;
+    const int E = (vec32 && nc % 2 == 0) ? nc * nc / 2 : nc * nc;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
     dim3 grid(gx, gy), block(BLOCK);
-#define QMG_ELEM_LAUNCH(NC)                                                                   \
+#define QMG_ELEM_LAUNCH_T(T, NC)                                                              \
     switch (g_stencil_nt & 3) {                                                               \
-      case 0: k_stencil_elem<NC, false, false><<<grid, block, 0, st>>>(a); break;             \
-      case 1: k_stencil_elem<NC, true, false><<<grid, block, 0, st>>>(a); break;              \
-      case 2: k_stencil_elem<NC, false, true><<<grid, block, 0, st>>>(a); break;              \
-      default: k_stencil_elem<NC, true, true><<<grid, block, 0, st>>>(a); break;              \
+      case 0: k_stencil_elem<T, NC, false, false><<<grid, block, 0, st>>>(a); break;          \
+      case 1: k_stencil_elem<T, NC, true, false><<<grid, block, 0, st>>>(a); break;           \
+      case 2: k_stencil_elem<T, NC, false, true><<<grid, block, 0, st>>>(a); break;           \
+      default: k_stencil_elem<T, NC, true, true><<<grid, block, 0, st>>>(a); break;           \
     }
+#define QMG_ELEM_LAUNCH(NC) if (vec32) { QMG_ELEM_LAUNCH_T(float, NC) } else { QMG_ELEM_LAUNCH_T(double, NC) }
     if (nc == 1) { QMG_ELEM_LAUNCH(1) }
     if (nc == 2) { QMG_ELEM_LAUNCH(2) }
     if (nc == 4) { QMG_ELEM_LAUNCH(4) }
 #undef QMG_ELEM_LAUNCH
+#undef QMG_ELEM_LAUNCH_T
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }
@@ -1043,20 +1165,21 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     dim3 grid(gx, gy), block(BLOCK);
     for (int k0 = 0; k0 < a.nrhs; k0 += 16) {
       StencilArgs b = a;
-      b.lhs = a.lhs + (long)k0 * a.vec_stride;
-      b.rhs = a.rhs + (long)k0 * a.vec_stride;
+      b.lhs = (char*)a.lhs + (size_t)k0 * a.vec_stride * (vec32 ? 8 : 16);
+      b.rhs = (const char*)a.rhs + (size_t)k0 * a.vec_stride * (vec32 ? 8 : 16);
       const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
       const size_t smem = a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * nc * (nc + 2) : sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
       const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
-#define QMG_MFMA_LAUNCH1(NC, MODE, M32)                                                                         \
+#define QMG_MFMA_LAUNCH1(NC, MODE, M32, V32)                                                                    \
       {                                                                                                         \
         if (smem > 64 * 1024)                                                                                   \
-          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, M32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        k_stencil_mfma<NC, MODE, M32><<<grid, block, smem, st>>>(b, nk);                                        \
+          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, M32, V32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        k_stencil_mfma<NC, MODE, M32, V32><<<grid, block, smem, st>>>(b, nk);                                   \
       }
+#define QMG_MFMA_LAUNCH2(NC, MODE)                                                                              \
+      { if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
-      if (mode == 0) { if (a.mat32) QMG_MFMA_LAUNCH1(NC, 0, true) else QMG_MFMA_LAUNCH1(NC, 0, false) }          \
-      else { if (a.mat32) QMG_MFMA_LAUNCH1(NC, 1, true) else QMG_MFMA_LAUNCH1(NC, 1, false) }
+      if (mode == 0) QMG_MFMA_LAUNCH2(NC, 0) else QMG_MFMA_LAUNCH2(NC, 1)
       switch (nc) {
         case 8: QMG_MFMA_LAUNCH(8) break;
         case 12: QMG_MFMA_LAUNCH(12) break;
@@ -1066,6 +1189,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       }
 #undef QMG_MFMA_LAUNCH
 #undef QMG_MFMA_LAUNCH1
+#undef QMG_MFMA_LAUNCH2
     }
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
@@ -1084,7 +1208,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       if (smem <= 64 * 1024) {
         const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
         dim3 grid(gx, gy), block(BLOCK);
-#define QMG_G32_CASE2(PP, KR) k_stencil_gen32<PP, KR><<<grid, block, smem, st>>>(a, nc, L);
+#define QMG_G32_CASE2(PP, KR) { if (a.vec32) k_stencil_gen32<PP, KR, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, KR, false><<<grid, block, smem, st>>>(a, nc, L); }
 #define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else { QMG_G32_CASE2(PP, 1) } } break;
         switch (pp) { QMG_G32_CASE(1) QMG_G32_CASE(2) QMG_G32_CASE(3) QMG_G32_CASE(4) QMG_G32_CASE(5) QMG_G32_CASE(6) default: break; }
 #undef QMG_G32_CASE
@@ -1106,12 +1230,13 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
-#define QMG_GEN_CASE2(PT, M32, KR)                                                                      \
+#define QMG_GEN_CASE3(PT, M32, KR, V32)                                                                 \
     {                                                                                                   \
       if (smem > 64 * 1024)                                                                             \
-        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32, KR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-      k_stencil_gen<PT, M32, KR><<<grid, block, smem, st>>>(a, nc, L);                                  \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32, KR, V32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      k_stencil_gen<PT, M32, KR, V32><<<grid, block, smem, st>>>(a, nc, L);                             \
     }
+#define QMG_GEN_CASE2(PT, M32, KR) { if (M32 && a.vec32) QMG_GEN_CASE3(PT, true, KR, true) else QMG_GEN_CASE3(PT, M32, KR, false) }
 #define QMG_GEN_CASE1(PT, M32)                                                                          \
     { if (kr == 8) QMG_GEN_CASE2(PT, M32, 8) else if (kr == 4) QMG_GEN_CASE2(PT, M32, 4) else QMG_GEN_CASE2(PT, M32, 1) }
 #define QMG_GEN_CASE(PT)                                                                                \
@@ -1126,6 +1251,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #undef QMG_GEN_CASE
 #undef QMG_GEN_CASE1
 #undef QMG_GEN_CASE2
+#undef QMG_GEN_CASE3
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

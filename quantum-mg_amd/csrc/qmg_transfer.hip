@@ -29,8 +29,10 @@ __device__ __forceinline__ long coarse_site_index(const XferGeom& g, int cx, int
 }
 
 // ---------------- prolong: fine[k] += sum_d null[d][k] * coarse[ci(k)*cnc + d] ----------------
-__global__ __launch_bounds__(BLOCK) void k_prolong(const cplx* __restrict__ nullv, int nvec, const cplx* __restrict__ coarse,
-                                                   cplx* __restrict__ fine, const XferGeom g) {
+// T = storage scalar of the null vectors and of both vectors; arithmetic in fp64 registers.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse,
+                                                   void* __restrict__ fine, const XferGeom g) {
   const long row_elems = (long)g.fhr * g.fnc;
   const int nrows = 2 * g.fLy;
   for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
@@ -42,23 +44,19 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const cplx* __restrict__ null
       const int cx = (2 * j + s) / g.bx;
       const long ci = coarse_site_index(g, cx, cy);
       const long k = ((long)p * g.fhalf_vol + (long)y * g.fhr) * g.fnc + t;
-      const cplx* cv = coarse + ci * g.cnc;
-      cplx acc = fine[k];
+      const long cv = ci * g.cnc;
+      cplx acc = ldc<T>(fine, k);
       // the null vectors are read exactly once: non-temporal, 8 loads in flight per lane before the FMAs
       int d = 0;
       for (; d + 8 <= nvec; d += 8) {
         cplx v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const cplx* src = nullv + (long)(d + q) * g.fsize + k;
-          v[q].x = __builtin_nontemporal_load(&src->x);
-          v[q].y = __builtin_nontemporal_load(&src->y);
-        }
+        for (int q = 0; q < 8; q++) v[q] = ldc_nt<T>(nullv, (long)(d + q) * g.fsize + k);
 #pragma unroll
-        for (int q = 0; q < 8; q++) cmac(acc, v[q], cv[d + q]);
+        for (int q = 0; q < 8; q++) cmac(acc, v[q], ldc<T>(coarse, cv + d + q));
       }
-      for (; d < nvec; d++) cmac(acc, nullv[(long)d * g.fsize + k], cv[d]);
-      fine[k] = acc;
+      for (; d < nvec; d++) cmac(acc, ldc<T>(nullv, (long)d * g.fsize + k), ldc<T>(coarse, cv + d));
+      stc<T>(fine, k, acc);
     }
   }
 }
@@ -69,8 +67,9 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const cplx* __restrict__ null
 // null vectors at a time in registers; LDS sums the TPG partials.  One writer per (site, d): no atomics.
 constexpr int XFER_DC = 8;
 
-__global__ __launch_bounds__(BLOCK) void k_restrict(const cplx* __restrict__ nullv, int nvec, const cplx* __restrict__ fine,
-                                                    cplx* __restrict__ coarse, const XferGeom g, int NG, int TPG) {
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine,
+                                                    void* __restrict__ coarse, const XferGeom g, int NG, int TPG) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* red = reinterpret_cast<cplx*>(smem_raw);   // [BLOCK][XFER_DC]
   const int G = (g.bx / 2) * g.fnc;
@@ -92,16 +91,10 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const cplx* __restrict__ nul
           const long base = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc;
           for (int el = l; el < G; el += TPG) {
             const long k = base + el;
-            const cplx f = fine[k];
+            const cplx f = ldc<T>(fine, k);
 #pragma unroll
             for (int q = 0; q < XFER_DC; q++)
-              if (q < dn) {   // read-once stream: non-temporal
-                const cplx* src = nullv + (long)(d0 + q) * g.fsize + k;
-                cplx nvq;
-                nvq.x = __builtin_nontemporal_load(&src->x);
-                nvq.y = __builtin_nontemporal_load(&src->y);
-                cmac_conj(acc[q], nvq, f);
-              }
+              if (q < dn) cmac_conj(acc[q], ldc_nt<T>(nullv, (long)(d0 + q) * g.fsize + k), f);   // read-once stream: non-temporal
           }
         }
       }
@@ -117,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const cplx* __restrict__ nul
         cplx t = cmake(0.0, 0.0);
         for (int u = 0; u < TPG; u++) t = cadd(t, red[(g2 * TPG + u) * XFER_DC + q]);
         const long o = coarse_site_index(g, cx2, cy) * g.cnc + d0 + q;
-        coarse[o] = cadd(coarse[o], t);
+        stc<T>(coarse, o, cadd(ldc<T>(coarse, o), t));
       }
     }
     __syncthreads();
@@ -125,8 +118,9 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const cplx* __restrict__ nul
 }
 
 // Generic fallback (odd bx, bx = 1, ...): one thread per (coarse site, d), walking the block by coordinates.
-__global__ __launch_bounds__(BLOCK) void k_restrict_generic(const cplx* __restrict__ nullv, int nvec, const cplx* __restrict__ fine,
-                                                            cplx* __restrict__ coarse, const XferGeom g) {
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_restrict_generic(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine,
+                                                            void* __restrict__ coarse, const XferGeom g) {
   const int cLx = 2 * g.chr;
   const long total = (long)cLx * g.cLy * nvec;
   for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (long)gridDim.x * BLOCK) {
@@ -141,11 +135,155 @@ __global__ __launch_bounds__(BLOCK) void k_restrict_generic(const cplx* __restri
         const long site = (long)(y + p * g.fLy) * g.fhr + (x >> 1);
         for (int c = 0; c < g.fnc; c++) {
           const long k = site * g.fnc + c;
-          cmac_conj(acc, nullv[(long)d * g.fsize + k], fine[k]);
+          cmac_conj(acc, ldc<T>(nullv, (long)d * g.fsize + k), ldc<T>(fine, k));
         }
       }
     const long o = coarse_site_index(g, cx, cy) * g.cnc + d;
-    coarse[o] = cadd(coarse[o], acc);
+    stc<T>(coarse, o, cadd(ldc<T>(coarse, o), acc));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Transfer for a lock-step batch (2..16 systems): the null vectors -- nvec of the (nvec + 2k) size_cv_f complex a call
+// moves, and the same for every system -- are streamed ONCE for up to KB systems.  Both kernels work on the fine elements
+// that consecutive coarse sites of one coarse row own: 2*by fine half-rows (both parities) x G = (bx/2)*fnc contiguous
+// elements per site, so every wavefront access is whole 128-byte lines.
+//
+// Prolong: the coarse values of a tile of SX sites (SX x nvec x KB complex, a few KB) are staged in LDS once; a thread
+// owns a fine element, streams its nvec null-vector entries non-temporally (4 in flight) and reads the KB coarse values
+// of each d as LDS broadcasts (all lanes of a site read the same address; the site stride is padded so that different
+// sites of a row hit different banks).  (The first version looped 8 x nvec coarse values per element through L1:
+// address-bound at 2 TB/s, profiles/r01_kernel_rooflines.json.)
+template <typename T, int KB>
+__global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse, void* __restrict__ fine,
+                                                         const XferGeom g, const BatchIdx bi, int s0, long cstride, long fstride, int SX) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  cplx* cl = reinterpret_cast<cplx*>(smem_raw);          // [SX][nvec * KB + 1]
+  const int ns = (bi.n - s0 < KB) ? bi.n - s0 : KB;
+  const int G = (g.bx / 2) * g.fnc, R = 2 * g.by;
+  const int cLx = 2 * g.chr;
+  const int cx0 = blockIdx.x * SX;
+  const int nsx = (cLx - cx0 < SX) ? cLx - cx0 : SX;
+  const int sstride = nvec * KB + 1;
+  long fo[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) fo[q] = (long)bi.id[s0 + ((q < ns) ? q : 0)] * fstride;   // unused slots alias slot 0 (computed, discarded)
+  for (int cy = blockIdx.y; cy < g.cLy; cy += gridDim.y) {
+    __syncthreads();   // the previous tile's reads are done
+    for (int t = threadIdx.x; t < nsx * KB * nvec; t += BLOCK) {   // d fastest: coalesced runs of nvec coarse values
+      const int d = t % nvec, q = (t / nvec) % KB, s = t / (nvec * KB);
+      const long ci = coarse_site_index(g, cx0 + s, cy);
+      cl[s * sstride + d * KB + q] = (q < ns) ? ldc<T>(coarse, (long)bi.id[s0 + q] * cstride + ci * g.cnc + d) : cmake(0.0, 0.0);
+    }
+    __syncthreads();
+    const int row_w = nsx * G;
+    for (int t = threadIdx.x; t < R * row_w; t += BLOCK) {
+      const int rr = t / row_w, u = t - rr * row_w, s = u / G;
+      const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
+      const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx0 * (g.bx / 2)) * g.fnc + u;
+      const cplx* cs = cl + s * sstride;
+      cplx acc[KB];
+#pragma unroll
+      for (int q = 0; q < KB; q++) acc[q] = ldc<T>(fine, fo[q] + e);
+      int d = 0;
+      for (; d + 4 <= nvec; d += 4) {
+        cplx nv[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) nv[w] = ldc_nt<T>(nullv, (long)(d + w) * g.fsize + e);
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+          for (int q = 0; q < KB; q++) cmac(acc[q], nv[w], cs[(d + w) * KB + q]);
+      }
+      for (; d < nvec; d++) {
+        const cplx nv = ldc_nt<T>(nullv, (long)d * g.fsize + e);
+#pragma unroll
+        for (int q = 0; q < KB; q++) cmac(acc[q], nv, cs[d * KB + q]);
+      }
+#pragma unroll
+      for (int q = 0; q < KB; q++)
+        if (q < ns) stc<T>(fine, fo[q] + e, acc[q]);
+    }
+  }
+}
+
+// Restrict: a half wavefront (32 lanes) owns one coarse site, a workgroup 8 consecutive sites of a coarse row.  Lane l
+// walks elements l, l+32, ... of the site's block (row-major over its 2*by runs of G elements), keeps the KB fine values
+// of an element in registers and accumulates DC = 32/KB null vectors x KB systems of partial sums (64 doubles).  The sum
+// over the 32 lanes is a RECURSIVE HALVING: at step m in {1,2,4,8,16} a lane keeps the half of its values selected by
+// bit m of its id and adds the partner's (lane ^ m) copy of that half -- 32+16+8+4+2 = 62 exchanges instead of the
+// 64 x 5 of a plain butterfly (which made the first version shuffle-bound) -- and ends with ONE complex sum, the one
+// for (d, system) = bit-reversed lane id: one writer per output, fixed order, deterministic.
+template <typename T, int KB>
+__global__ __launch_bounds__(BLOCK) void k_brestrict_tile(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine, void* __restrict__ coarse,
+                                                          const XferGeom g, const BatchIdx bi, int s0, long cstride, long fstride) {
+  constexpr int DC = 32 / KB;        // null vectors per pass
+  constexpr int NV = 64;             // doubles per lane per pass: DC * KB complex
+  const int ns = (bi.n - s0 < KB) ? bi.n - s0 : KB;
+  const int cLx = 2 * g.chr;
+  const long ncs = (long)cLx * g.cLy;
+  const int G = (g.bx / 2) * g.fnc;
+  const int nel = 2 * g.by * G;
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+  long fo[KB];
+#pragma unroll
+  for (int q = 0; q < KB; q++) fo[q] = (long)bi.id[s0 + ((q < ns) ? q : 0)] * fstride;
+  // the (d, system) pair this lane ends up holding: bit-reversed lane id
+  const int pair = ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4);
+  const int my_dq = pair / KB, my_q = pair - my_dq * KB;
+  for (long cs = (long)blockIdx.x * (BLOCK / 32) + grp; cs < ncs; cs += (long)gridDim.x * (BLOCK / 32)) {
+    const int cy = (int)(cs / cLx), cx = (int)(cs - (long)cy * cLx);
+    const long ci = coarse_site_index(g, cx, cy);
+    for (int d0 = 0; d0 < nvec; d0 += DC) {
+      const int dn = (nvec - d0 < DC) ? nvec - d0 : DC;
+      double v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; i++) v[i] = 0.0;
+      for (int t = l; t < nel; t += 32) {
+        const int rr = t / G, el = t - rr * G;
+        const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
+        const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc + el;
+        cplx f[KB];
+#pragma unroll
+        for (int q = 0; q < KB; q++) f[q] = ldc<T>(fine, fo[q] + e);
+#pragma unroll
+        for (int dq = 0; dq < DC; dq++) {
+          if (dq < dn) {
+            const cplx nv = ldc_nt<T>(nullv, (long)(d0 + dq) * g.fsize + e);
+#pragma unroll
+            for (int q = 0; q < KB; q++) {   // += conj(nv) f
+              double& ar = v[(dq * KB + q) * 2];
+              double& ai = v[(dq * KB + q) * 2 + 1];
+              ar = fma(nv.x, f[q].x, ar); ar = fma(nv.y, f[q].y, ar);
+              ai = fma(nv.x, f[q].y, ai); ai = fma(-nv.y, f[q].x, ai);
+            }
+          }
+        }
+      }
+      // recursive halving over the 32 lanes of the group (all index arithmetic is compile-time after unrolling)
+#pragma unroll
+      for (int step = 0; step < 5; step++) {
+        const int m = 1 << step;
+        const int half = NV >> (step + 1);
+        const bool up = (l & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+          const double lo = v[i], hi = v[i + half];
+          const double send = up ? lo : hi;
+          const double keep = up ? hi : lo;
+          double recv;
+          if (m == 1) recv = lane_xor1(send);
+          else if (m == 2) recv = lane_xor2(send);
+          else recv = __shfl_xor(send, m);
+          v[i] = keep + recv;
+        }
+      }
+      if (my_dq < dn && my_q < ns) {
+        const long o = (long)bi.id[s0 + my_q] * cstride + ci * g.cnc + d0 + my_dq;
+        const cplx c = ldc<T>(coarse, o);
+        stc<T>(coarse, o, cmake(c.x + v[0], c.y + v[1]));
+      }
+    }
   }
 }
 
@@ -210,6 +348,7 @@ static int make_geom(XferGeom* g, int fLx, int fLy, int fnc, int cLx, int cLy, i
   return QMG_SUCCESS;
 }
 
+template <typename T>
 static int launch_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse, const XferGeom& g, hipStream_t st) {
   if ((g.bx & 1) == 0) {
     const int G = (g.bx / 2) * g.fnc;
@@ -219,22 +358,85 @@ static int launch_restrict(const void* nullvecs, int nvec, const void* fine, voi
     if (NG > cLx) NG = cLx;
     const int TPG = BLOCK / NG;
     dim3 grid((unsigned)((cLx + NG - 1) / NG), g.cLy > 65535 ? 65535 : g.cLy);
-    k_restrict<<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>((const cplx*)nullvecs, nvec, (const cplx*)fine, (cplx*)coarse, g, NG, TPG);
+    k_restrict<T><<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>(nullvecs, nvec, fine, coarse, g, NG, TPG);
   } else {
-    k_restrict_generic<<<grid_1d((size_t)4 * g.chalf_vol * nvec / 2), BLOCK, 0, st>>>((const cplx*)nullvecs, nvec, (const cplx*)fine, (cplx*)coarse, g);
+    k_restrict_generic<T><<<grid_1d((size_t)4 * g.chalf_vol * nvec / 2), BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g);
   }
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
 
+template <typename T>
 static int launch_prolong(const void* nullvecs, int nvec, const void* coarse, void* fine, const XferGeom& g, hipStream_t st) {
   const long row_elems = (long)g.fhr * g.fnc;
   unsigned gx = (unsigned)((row_elems + BLOCK - 1) / BLOCK);
   if (gx > 1024) gx = 1024;
   const int nrows = 2 * g.fLy;
   dim3 grid(gx, nrows > 65535 ? 65535 : nrows);
-  k_prolong<<<grid, BLOCK, 0, st>>>((const cplx*)nullvecs, nvec, (const cplx*)coarse, (cplx*)fine, g);
+  k_prolong<T><<<grid, BLOCK, 0, st>>>(nullvecs, nvec, coarse, fine, g);
   QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+int g_xfer_tile = 1;   // tuning knob "xfer_tile": 1 = batched transfer as LDS-tiled kernels, 0 = system by system
+
+// sites per prolong tile: a fine half-row segment of at least 512 bytes where the lattice allows, LDS <= 48 KB
+static int prolong_tile_sites(const XferGeom& g, int nvec, int KB) {
+  const int G = (g.bx / 2) * g.fnc;
+  int SX = (32 + G - 1) / G;
+  if (SX < 1) SX = 1;
+  if (SX > 2 * g.chr) SX = 2 * g.chr;
+  while (SX > 1 && (size_t)SX * (nvec * KB + 1) * sizeof(cplx) > 48 * 1024) SX--;
+  return SX;
+}
+
+template <typename T>
+static int prolong_batch_impl(const void* nullvecs, int nvec, const void* coarse, void* fine, const XferGeom& g, const BatchIdx& bi, size_t cstride,
+                              size_t fstride, hipStream_t st) {
+  typedef typename CStore<T>::type ct;
+  if (bi.n == 1 || !g_xfer_tile || (g.bx & 1)) {   // one system (or an odd block width): the single-vector kernel, system by system
+    for (int s = 0; s < bi.n; s++) {
+      const int rc = launch_prolong<T>(nullvecs, nvec, (const ct*)coarse + (size_t)bi.id[s] * cstride, (ct*)fine + (size_t)bi.id[s] * fstride, g, st);
+      if (rc) return rc;
+    }
+    return QMG_SUCCESS;
+  }
+  for (int s0 = 0; s0 < bi.n; s0 += 8) {
+    const int left = bi.n - s0;
+    const int KB = left > 4 ? 8 : left > 2 ? 4 : 2;
+    const int SX = prolong_tile_sites(g, nvec, KB);
+    const size_t smem = (size_t)SX * (nvec * KB + 1) * sizeof(cplx);
+    if (smem > 64 * 1024) return QMG_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((2 * g.chr + SX - 1) / SX), g.cLy > 65535 ? 65535 : g.cLy);
+    if (KB == 8) k_bprolong_tile<T, 8><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
+    else if (KB == 4) k_bprolong_tile<T, 4><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
+    else k_bprolong_tile<T, 2><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
+    QMG_LAUNCH_CHECK();
+  }
+  return QMG_SUCCESS;
+}
+
+template <typename T>
+static int restrict_batch_impl(const void* nullvecs, int nvec, const void* fine, void* coarse, const XferGeom& g, const BatchIdx& bi, size_t fstride,
+                               size_t cstride, hipStream_t st) {
+  typedef typename CStore<T>::type ct;
+  if (bi.n == 1 || !g_xfer_tile || (g.bx & 1)) {
+    for (int s = 0; s < bi.n; s++) {
+      const int rc = launch_restrict<T>(nullvecs, nvec, (const ct*)fine + (size_t)bi.id[s] * fstride, (ct*)coarse + (size_t)bi.id[s] * cstride, g, st);
+      if (rc) return rc;
+    }
+    return QMG_SUCCESS;
+  }
+  const long ncs = 2 * g.chalf_vol;
+  const long nblk = (ncs + BLOCK / 32 - 1) / (BLOCK / 32);
+  const unsigned gx = (unsigned)(nblk > 262144 ? 262144 : nblk);
+  for (int s0 = 0; s0 < bi.n; s0 += 8) {
+    const int left = bi.n - s0;
+    if (left > 4) k_brestrict_tile<T, 8><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
+    else if (left > 2) k_brestrict_tile<T, 4><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
+    else k_brestrict_tile<T, 2><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
+    QMG_LAUNCH_CHECK();
+  }
   return QMG_SUCCESS;
 }
 
@@ -250,7 +452,7 @@ int qmg_prolong(const void* nullvecs, int nvec, const void* coarse, void* fine,
   XferGeom g;
   int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
   if (rc) return rc;
-  return launch_prolong(nullvecs, nvec, coarse, fine, g, as_stream(stream));
+  return launch_prolong<double>(nullvecs, nvec, coarse, fine, g, as_stream(stream));
 }
 
 int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
@@ -259,7 +461,41 @@ int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
   XferGeom g;
   int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
   if (rc) return rc;
-  return launch_restrict(nullvecs, nvec, fine, coarse, g, as_stream(stream));
+  return launch_restrict<double>(nullvecs, nvec, fine, coarse, g, as_stream(stream));
+}
+
+// transfer.h:455-511 for a lock-step batch, either storage precision
+int qmg_prolong_batch_t(int dtype, const void* nullvecs, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                        int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream) {
+  if (!valid_dtype(dtype) || !nullvecs || !coarse || !fine || nvec < 1 || nrhs < 1 || nrhs > BATCH_MAX) return QMG_ERR_INVALID;
+  XferGeom g;
+  int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
+  if (rc) return rc;
+  if (nvec != cnc) return QMG_ERR_INVALID;
+  const BatchIdx bi = expand_mask(mask, nrhs);
+  if (bi.n == 0) return QMG_SUCCESS;
+  if (dtype == QMG_C32) return prolong_batch_impl<float>(nullvecs, nvec, coarse, fine, g, bi, cstride, fstride, as_stream(stream));
+  return prolong_batch_impl<double>(nullvecs, nvec, coarse, fine, g, bi, cstride, fstride, as_stream(stream));
+}
+int qmg_prolong_batch(const void* nullvecs, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                      int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream) {
+  return qmg_prolong_batch_t(QMG_C64, nullvecs, nvec, coarse, fine, fLx, fLy, fnc, cLx, cLy, cnc, nrhs, cstride, fstride, mask, stream);
+}
+int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                         int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream) {
+  if (!valid_dtype(dtype) || !nullvecs || !coarse || !fine || nvec < 1 || nrhs < 1 || nrhs > BATCH_MAX) return QMG_ERR_INVALID;
+  XferGeom g;
+  int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
+  if (rc) return rc;
+  if (nvec != cnc) return QMG_ERR_INVALID;
+  const BatchIdx bi = expand_mask(mask, nrhs);
+  if (bi.n == 0) return QMG_SUCCESS;
+  if (dtype == QMG_C32) return restrict_batch_impl<float>(nullvecs, nvec, fine, coarse, g, bi, fstride, cstride, as_stream(stream));
+  return restrict_batch_impl<double>(nullvecs, nvec, fine, coarse, g, bi, fstride, cstride, as_stream(stream));
+}
+int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                       int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream) {
+  return qmg_restrict_batch_t(QMG_C64, nullvecs, nvec, fine, coarse, fLx, fLy, fnc, cLx, cLy, cnc, nrhs, fstride, cstride, mask, stream);
 }
 
 // block_orthonormalize (transfer.h:514-607): the reference's own formulation -- classical
@@ -283,19 +519,19 @@ int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc
     for (int j = 0; j < i && !rc; j++) {
       hipMemsetAsync(fine1, 0, sizeof(cplx) * fsize, st);
       hipMemsetAsync(coarse2, 0, sizeof(cplx) * csize, st);
-      rc = launch_restrict(nv + j * fsize, 1, nv + i * fsize, coarse2, g, st);            // <v_i, v_j> per block (:552)
+      rc = launch_restrict<double>(nv + j * fsize, 1, nv + i * fsize, coarse2, g, st);            // <v_i, v_j> per block (:552)
       if (!rc && cholesky) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)cholesky, coarse2, cvol, cnc, j * cnc + i, 0);   // :560
-      if (!rc) rc = launch_prolong(nv + j * fsize, 1, coarse2, fine1, g, st);             // <v_i, v_j> v_j (:565)
+      if (!rc) rc = launch_prolong<double>(nv + j * fsize, 1, coarse2, fine1, g, st);             // <v_i, v_j> v_j (:565)
       if (!rc) rc = qmg_caxpy(-1.0, 0.0, fine1, nv + i * fsize, (size_t)fsize, stream);   // :569
     }
     if (rc) break;
     hipMemsetAsync(fine1, 0, sizeof(cplx) * fsize, st);
     hipMemsetAsync(coarse2, 0, sizeof(cplx) * csize, st);
-    rc = launch_restrict(nv + i * fsize, 1, nv + i * fsize, coarse2, g, st);              // :579
+    rc = launch_restrict<double>(nv + i * fsize, 1, nv + i * fsize, coarse2, g, st);              // :579
     if (rc) break;
     k_inv_real_sqrt<<<grid_1d((size_t)csize), BLOCK, 0, st>>>(coarse2, csize);            // :583
     if (cholesky) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)cholesky, coarse2, cvol, cnc, i * (cnc + 1), 1);   // :588-593
-    rc = launch_prolong(nv + i * fsize, 1, coarse2, fine1, g, st);                        // :598
+    rc = launch_prolong<double>(nv + i * fsize, 1, coarse2, fine1, g, st);                        // :598
     if (rc) break;
     hipMemcpyAsync(nv + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);   // :601
   }
@@ -328,30 +564,30 @@ int qmg_block_bi_orthonormalize(void* pvecs, void* rvecs, int nvec, int fLx, int
   for (int i = 0; i < nvec && !rc; i++) {
     for (int j = 0; j < i && !rc; j++) {
       zero();
-      rc = launch_restrict(R + j * fsize, 1, P + i * fsize, coarse2, g, st);                                        // <r_j, p_i>  (:643)
+      rc = launch_restrict<double>(R + j * fsize, 1, P + i * fsize, coarse2, g, st);                                        // <r_j, p_i>  (:643)
       if (!rc && block_U) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_U, coarse2, cvol, cnc, j * cnc + i, 0);   // :651
-      if (!rc) rc = launch_prolong(P + j * fsize, 1, coarse2, fine1, g, st);                                        // :656
+      if (!rc) rc = launch_prolong<double>(P + j * fsize, 1, coarse2, fine1, g, st);                                        // :656
       if (!rc) rc = qmg_caxpy(-1.0, 0.0, fine1, P + i * fsize, (size_t)fsize, stream);                              // :660
       if (rc) break;
       zero();
-      rc = launch_restrict(P + j * fsize, 1, R + i * fsize, coarse2, g, st);                                        // <p_j, r_i>  (:668)
+      rc = launch_restrict<double>(P + j * fsize, 1, R + i * fsize, coarse2, g, st);                                        // <p_j, r_i>  (:668)
       if (!rc && block_L) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_L, coarse2, cvol, cnc, i * cnc + j, 0);   // :678
-      if (!rc) rc = launch_prolong(R + j * fsize, 1, coarse2, fine1, g, st);                                        // :683
+      if (!rc) rc = launch_prolong<double>(R + j * fsize, 1, coarse2, fine1, g, st);                                        // :683
       if (!rc) rc = qmg_caxpy(-1.0, 0.0, fine1, R + i * fsize, (size_t)fsize, stream);                              // :687
     }
     if (rc) break;
     zero();
-    rc = launch_restrict(R + i * fsize, 1, P + i * fsize, coarse2, g, st);                                          // <r_i, p_i>  (:699)
+    rc = launch_restrict<double>(R + i * fsize, 1, P + i * fsize, coarse2, g, st);                                          // <r_i, p_i>  (:699)
     if (rc) break;
     k_elementwise<0><<<grid_1d((size_t)csize), BLOCK, 0, st>>>(coarse2, csize);                                     // inv_phase_abs_sqrt (:703)
     if (block_L) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_L, coarse2, cvol, cnc, i * (cnc + 1), 1);   // :708-719
-    rc = launch_prolong(R + i * fsize, 1, coarse2, fine1, g, st);                                                   // :724
+    rc = launch_prolong<double>(R + i * fsize, 1, coarse2, fine1, g, st);                                                   // :724
     if (rc) break;
     hipMemcpyAsync(R + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);                        // :727
     hipMemsetAsync(fine1, 0, sizeof(cplx) * fsize, st);
     k_elementwise<1><<<grid_1d((size_t)csize), BLOCK, 0, st>>>(coarse2, csize);                                     // abs_vector (:731)
     if (block_U) k_chol_store<<<grid_1d((size_t)cvol), BLOCK, 0, st>>>((cplx*)block_U, coarse2, cvol, cnc, i * (cnc + 1), 1);   // :735-742
-    rc = launch_prolong(P + i * fsize, 1, coarse2, fine1, g, st);                                                   // :747
+    rc = launch_prolong<double>(P + i * fsize, 1, coarse2, fine1, g, st);                                                   // :747
     if (rc) break;
     hipMemcpyAsync(P + i * fsize, fine1, sizeof(cplx) * fsize, hipMemcpyDeviceToDevice, st);                        // :750
   }
@@ -383,12 +619,12 @@ int qmg_coarse_build(void* cclover, void* chopping, const qmg_stencil_desc* fine
   auto probe = [&](int color, long lo, long hi, unsigned pieces) -> int {
     k_unit_probe<<<grid_1d((size_t)csize), BLOCK, 0, st>>>(tc, cvol, cnc, color, lo, hi);
     hipMemsetAsync(tf, 0, sizeof(cplx) * fsize, st);
-    int r = launch_prolong(nullvecs, cnc, tc, tf, g, st);
+    int r = launch_prolong<double>(nullvecs, cnc, tc, tf, g, st);
     if (r) return r;
     r = qmg_stencil_apply(fine, taf, tf, pieces | QMG_P_ZERO, 1, 0, stream);
     if (r) return r;
     hipMemsetAsync(tc, 0, sizeof(cplx) * csize, st);
-    return launch_restrict(rvecs, cnc, taf, tc, g, st);
+    return launch_restrict<double>(rvecs, cnc, taf, tc, g, st);
   };
   rc = QMG_SUCCESS;
   for (int color = 0; color < cnc && !rc; color++) {

@@ -15,15 +15,24 @@
 #include "../include/qmg/qmg.hpp"
 
 // verify_mode: 0 none, 1 every system, 2 system 0 only.  Returns true when every system converged (and verified).
+// f32_kcycle (or QMG_F32_KCYCLE in the environment): the K-cycle that preconditions the fp64 outer VPGCR runs entirely in
+// complex<float> on the fp32 shadow of the hierarchy (include/qmg/batch.hpp mg_preconditioner_batch_mixed) -- the fp32
+// instantiation BASELINE configs[4] names.  The outer solve, its tolerance and the true-residual check stay fp64.
 inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int nrhs, unsigned long long seed, double tol, int max_iter, int restart_freq,
                                   bool quiet, int verify_mode, double setup_s, void (*print_ops_stats)(void*), void* stats_arg,
-                                  QMGStencilType solve_type = QMG_MATVEC_ORIGINAL) {
+                                  QMGStencilType solve_type = QMG_MATVEC_ORIGINAL, bool f32_kcycle = false) {
   using namespace std;
   if (nrhs < 1) { std::cout << "[QMG-ERROR]: nrhs must be positive\n"; return false; }
   const size_t n = (size_t)lat0->get_size_cv_l();
   {
     BatchKcycle probe(mg, 1);
     if (!probe.supported() || !BatchOp::supported(solve_type)) { std::cout << "[QMG-ERROR]: the batched K-cycle implements the ORIGINAL and RIGHT_SCHUR configurations only.\n"; return false; }
+  }
+  if (getenv("QMG_F32_KCYCLE")) f32_kcycle = true;
+  if (f32_kcycle) {
+    BatchKcycle sh(mg, 1);
+    if (!sh.enable_f32_hierarchy()) { std::cout << "[QMG-ERROR]: could not build the fp32 shadow of the hierarchy\n"; return false; }
+    cout << "[QMG-INFO]: K-cycle preconditioner in fp32 (complex<float> vectors, matrices and null vectors; fp64 outer VPGCR)\n";
   }
   // batch size: what fits (an outer solve rarely needs its whole restart length; 48 directions is a safe expectation for
   // these K-cycles, and bgcr_core stops loudly if a basis vector cannot be allocated)
@@ -67,8 +76,8 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
         qmg::bzero(y, n, all);
         qmg_stream_sync(0);
         auto t0 = std::chrono::steady_clock::now();
-        inv = bgcr_core(y, b_prep, (int)(schur ? n / 2 : n), max_iter, tol, restart_freq, apply_stencil_typed_batch, (void*)&op0, mg_preconditioner_batch, (void*)&bk,
-                        all, true, &verb, "VPGCR-restart");
+        inv = bgcr_core<double>(y, b_prep, (int)(schur ? n / 2 : n), max_iter, tol, restart_freq, apply_stencil_typed_batch<double>, (void*)&op0,
+                                f32_kcycle ? mg_preconditioner_batch_mixed : mg_preconditioner_batch<double>, (void*)&bk, all, true, &verb, "VPGCR-restart");
         qmg_stream_sync(0);
         const double t_rep = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (repeats > 1) cout << "[QMG-MRHS]: repeat " << rep << " solve " << t_rep << " s\n";

@@ -75,6 +75,7 @@ inline int N13::build(int argc, char** argv) {
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4;
   tol = 1e-10; max_iter = 1000; restart_freq = 32;
+  if (getenv("QMG_MAX_ITER")) max_iter = atoi(getenv("QMG_MAX_ITER"));   // test hook: cap the outer iterations (residual-history comparisons)
   const double inner_tol = 0.2; const int inner_max_iter = 1000; const int inner_restart_freq = 32;
   const int n_pre_smooth = 2; const double pre_smooth_tol = 1e-15;
   const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;

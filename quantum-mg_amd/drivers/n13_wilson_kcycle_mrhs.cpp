@@ -1,6 +1,7 @@
 // n13_wilson_kcycle_mrhs -- the n13 K-cycle solve for a LOCK-STEP BATCH of independent right-hand sides on one GPU
 // (BASELINE configs[3]/[4]: independent right-hand sides, several per GPU; include/qmg/batch.hpp).
-//   ./n13_wilson_kcycle_mrhs L mass beta n_refine coarse_dof gauge_file tile nrhs [verify|verify0]
+//   ./n13_wilson_kcycle_mrhs L mass beta n_refine coarse_dof gauge_file tile nrhs [verify|verify0] [f32]
+// `f32` (or QMG_F32_KCYCLE=1): the K-cycle preconditioner runs in complex<float> on the fp32 shadow of the hierarchy (batch.hpp).
 // Setup is n13's (n13_setup.hpp).  Right-hand side k is the gaussian vector of seed (first solve seed)+k, so system 0
 // is exactly the system n13_wilson_kcycle solves.  All nrhs <= 16 systems advance through the same VPGCR / K-cycle
 // iteration together: every coarse operator and null vector is streamed once per step for the whole batch and the
@@ -26,7 +27,7 @@ int main(int argc, char** argv) {
   const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
   if (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1) cout << "[QMG-INFO]: rank " << rank << " of " << getenv("WORLD_SIZE") << " solves systems " << rank * nrhs << " .. " << (rank + 1) * nrhs - 1 << "\n";
   const bool ok_ = mrhs_solve_and_report(s.mg_object, s.lats[0], nrhs, s.seed + (unsigned long long)rank * nrhs, s.tol, s.max_iter, s.restart_freq, s.quiet, vmode, s.setup_s,
-                                         n13_print_stats, (void*)&s);
+                                         n13_print_stats, (void*)&s, QMG_MATVEC_ORIGINAL, std::string(argv[argc - 1]) == "f32");
   s.destroy();
   return ok_ ? 0 : 1;
 }

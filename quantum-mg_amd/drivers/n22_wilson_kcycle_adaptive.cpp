@@ -19,7 +19,10 @@
 // environment (torchrun sets them), every rank builds the same hierarchy, but the adaptive relaxations of a level are
 // SHARDED over the ranks (test vector j belongs to rank j mod world) and exchanged with ONE sum all-reduce per level
 // (qmg_allreduce_sum_f64, RCCL over xGMI; the vectors a rank does not own are zero in its buffer), after which all ranks
-// continue identically.  The 128-byte RCCL id travels through a file (QMG_COMM_ID_FILE, default /tmp/qmg_comm_id.<port>).
+// continue identically.  The 128-byte RCCL id comes through the launcher's rendezvous (qmg_comm_init_env: QMG_COMM_ID_HEX
+// or one TCP exchange with rank 0 on MASTER_ADDR:MASTER_PORT+1); a failure on one rank is made known to all ranks
+// (qmg_comm_all_ok) before the next collective, so nobody is left blocked.  UNVERIFIED on more than one GPU (the pool
+// has one-GPU boxes): exercised with a forced one-rank communicator and, on the host side, by two-process TCP tests.
 // In the solve every rank then takes its own right-hand side (seed + rank): the path's "independent right-hand sides".
 // solve_type (optional, not in n22): "schur" builds rbjacobi stencils on every level and solves as n19 does --
 // the "red-black preconditioned" variant of BASELINE configs[4].
@@ -29,10 +32,8 @@
 #include <iomanip>
 #include <iostream>
 #include <string>
-#include <fstream>
 #include <thread>
 #include <ctime>
-#include <sys/stat.h>
 
 #include "../include/qmg/qmg.hpp"
 #include "mrhs_solve.hpp"
@@ -103,32 +104,8 @@ int main(int argc, char** argv) {
   const int local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
   if (!qmg::ok(qmg_init(local_rank), "qmg_init")) return 2;
   const bool use_comm = world > 1 || getenv("QMG_COMM_FORCE_RCCL") != 0;
-  if (use_comm) {   // rank 0 creates the RCCL id and publishes it through a file; the others wait for it
-    const std::string idfile = getenv("QMG_COMM_ID_FILE") ? std::string(getenv("QMG_COMM_ID_FILE"))
-                                                          : std::string("/tmp/qmg_comm_id.") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "." +
-                                                                (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");   // unique per launch
-    char id[128];
-    if (rank == 0) {
-      if (!qmg::ok(qmg_comm_get_unique_id(id), "qmg_comm_get_unique_id")) return 2;
-      { std::ofstream f((idfile + ".tmp").c_str(), std::ios::binary); f.write(id, 128); }
-      std::rename((idfile + ".tmp").c_str(), idfile.c_str());
-    } else {
-      // a file left behind by an earlier launch on the same port must not be taken: accept only one written since shortly
-      // before this process started (the ranks of one launch start within a second of each other)
-      const time_t started = time(0);
-      bool got_id = false;
-      for (int tries = 0; tries < 600 && !got_id; tries++) {
-        struct stat st;
-        if (stat(idfile.c_str(), &st) == 0 && st.st_mtime >= started - 20) {
-          std::ifstream f(idfile.c_str(), std::ios::binary);
-          if (f && f.read(id, 128)) got_id = true;
-        }
-        if (!got_id) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-      }
-      if (!got_id) { cout << "[QMG-ERROR]: rank " << rank << " did not receive the RCCL id through " << idfile << "\n"; return 2; }
-    }
-    if (!qmg::ok(qmg_comm_init(id, world, rank), "qmg_comm_init")) return 2;
-    if (rank == 0 && world > 1) std::this_thread::sleep_for(std::chrono::milliseconds(500));   // let the others read before the file is reused
+  if (use_comm) {   // the RCCL id comes through the launcher's rendezvous (QMG_COMM_ID_HEX or one TCP exchange with rank 0; bounded waits)
+    if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env")) return 2;
     cout << "[QMG-INFO]: rank " << rank << " of " << world << " on device " << local_rank << "\n";
   }
   if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
@@ -138,9 +115,18 @@ int main(int argc, char** argv) {
   const int n_setup = stoi(argv[5]);
   const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
   const int tile = (argc > 7) ? stoi(argv[7]) : 64;
-  const bool schur = (argc > 8) && string(argv[8]) == "schur";
-  // "nrhs=K" (not in n22): after the reference's single solve, K more gaussian systems are solved in one lock-step batch
-  const int nrhs_batched = (argc > 8 && string(argv[8]).rfind("nrhs=", 0) == 0) ? stoi(string(argv[8]).substr(5)) : 0;
+  // options after `tile`, any order (none of them in n22): "schur" = solve as n19 does; "nrhs=K" = after the reference's single
+  // solve, K more gaussian systems in one lock-step batch; "f32" = those batched solves with the K-cycle in fp32
+  bool schur = false, f32 = false;
+  int nrhs_batched = 0;
+  for (int i = 8; i < argc; i++) {
+    const string o = argv[i];
+    if (o == "schur") schur = true;
+    else if (o == "f32") f32 = true;
+    else if (o.rfind("nrhs=", 0) == 0) nrhs_batched = stoi(o.substr(5));
+    else { std::cout << "Error: unknown option " << o << "\n"; return -1; }
+  }
+  if (f32 && nrhs_batched == 0) nrhs_batched = 1;
   const bool quiet = getenv("QMG_QUIET") != 0;
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4, coarse_dof = 8;
@@ -258,6 +244,14 @@ int main(int argc, char** argv) {
         std::vector<inversion_info> binv = bgcr_core(X, T, (int)n, 10, 1e-10, -1, apply_stencil_2D_M_batch, (void*)mg_object->get_stencil(fine_idx),
                                                      mg_preconditioner_batch, (void*)&bk, mine, true, &vq, "VPGCR");
         if (use_comm) {   // one collective per level: everybody gets every relaxed vector (foreign slots of X are still zero here)
+          bool local_ok = true;
+          for (int j = 0; j < nb; j++) if (qmg::is_active(mine, j) && !(binv[j].resSq == binv[j].resSq)) local_ok = false;   // a NaN relaxation on this rank
+          int all_ok = 0;
+          if (!qmg::ok(qmg_comm_all_ok(local_ok ? 1 : 0, &all_ok), "qmg_comm_all_ok") || !all_ok) {   // every rank learns of it BEFORE the data collective
+            cout << "[QMG-ERROR]: rank " << rank << ": a rank reported a failed relaxation; all ranks stop\n";
+            qmg_comm_finalize();
+            return 2;
+          }
           if (!qmg::ok(qmg_allreduce_sum_f64((double*)X.p, (size_t)2 * X.stride * nb, qmg::current_stream()), "qmg_allreduce_sum_f64")) return 2;
           qmg_stream_sync(qmg::current_stream());
         }
@@ -358,7 +352,7 @@ int main(int argc, char** argv) {
 
   bool ok_ = invif.success && true_res < 20 * tol;
   if (nrhs_batched > 0)
-    ok_ = mrhs_solve_and_report(mg_object, lats[0], nrhs_batched, g_seed, tol, max_iter, restart_freq, quiet, getenv("QMG_MRHS_VERIFY") ? 1 : 0, setup_s, 0, 0) && ok_;
+    ok_ = mrhs_solve_and_report(mg_object, lats[0], nrhs_batched, g_seed, tol, max_iter, restart_freq, quiet, getenv("QMG_MRHS_VERIFY") ? 1 : 0, setup_s, 0, 0, solve_type, f32) && ok_;
   delete mg_object;
   for (int i = 0; i < n_refine; i++) {
     delete transfer_objs[i]; delete level_solve_objs[i];
@@ -371,14 +365,6 @@ int main(int argc, char** argv) {
   delete[] lats;
   deallocate_vector(&gauge_field);
   qmg::VecPool::release_all();
-  if (use_comm) {
-    qmg_comm_finalize();
-    if (rank == 0) {
-      const std::string idfile = getenv("QMG_COMM_ID_FILE") ? std::string(getenv("QMG_COMM_ID_FILE"))
-                                                            : std::string("/tmp/qmg_comm_id.") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "." +
-                                                                  (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "run");
-      std::remove(idfile.c_str());
-    }
-  }
+  if (use_comm) qmg_comm_finalize();
   return ok_ ? 0 : 1;
 }

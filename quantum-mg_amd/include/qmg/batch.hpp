@@ -17,6 +17,13 @@
 // Schur complement (n19) on every level (stateful_multigrid.h:734-1060 with fine_stencil_app / coarsest_stencil_app in
 // {QMG_MATVEC_ORIGINAL, QMG_MATVEC_RIGHT_SCHUR}, no CGNE/CGNR smoothers).  Other configurations are rejected loudly
 // (BatchKcycle::supported), not emulated.
+//
+// Storage precision: every type and function here is a template on the storage scalar T of the batch vectors (double |
+// float).  T = double is the engine described above.  T = float is the fp32 instantiation of the path (BASELINE
+// configs[4]): the same K-cycle on complex<float> vectors, streaming the complex<float> shadow copies of every level's
+// matrices and null vectors (Stencil2D::enable_f32_shadow, TransferMG::enable_f32_shadow) through the QMG_C32 entry
+// points of the C-ABI; all scalars, inner products and convergence decisions stay fp64.  It is used as the preconditioner
+// of an fp64 flexible outer solve (mg_preconditioner_batch_mixed below), so the solution still reaches its fp64 tolerance.
 #ifndef QMG_BATCH_HPP
 #define QMG_BATCH_HPP
 
@@ -32,65 +39,77 @@ namespace qmg {
 
 const int BATCH_MAX = 16;
 
+template <typename T> struct dtype_of;
+template <> struct dtype_of<double> { enum { value = QMG_C64 }; };
+template <> struct dtype_of<float> { enum { value = QMG_C32 }; };
+
 // nrhs vectors, `stride` complex elements apart
-struct Batch {
-  complex<double>* p;
+template <typename T>
+struct BatchT {
+  complex<T>* p;
   size_t stride;
   int nrhs;
-  Batch() : p(0), stride(0), nrhs(0) {}
-  Batch(complex<double>* p_, size_t stride_, int nrhs_) : p(p_), stride(stride_), nrhs(nrhs_) {}
-  complex<double>* vec(int k) const { return p + (size_t)k * stride; }
+  BatchT() : p(0), stride(0), nrhs(0) {}
+  BatchT(complex<T>* p_, size_t stride_, int nrhs_) : p(p_), stride(stride_), nrhs(nrhs_) {}
+  complex<T>* vec(int k) const { return p + (size_t)k * stride; }
 };
+typedef BatchT<double> Batch;
 
 inline unsigned full_mask(int nrhs) { return (nrhs >= 32) ? 0xFFFFFFFFu : ((1u << nrhs) - 1u); }
 inline bool is_active(unsigned mask, int k) { return (mask >> k) & 1u; }
 
-// batch scratch, recycled like VecPool
-struct BatchPool {
+// batch scratch, recycled like VecPool (whose unit is one complex<double>: an fp32 batch takes half as many units)
+template <typename T>
+struct BatchPoolT {
   VecPool pool;
   size_t stride;
   int nrhs;
-  BatchPool(size_t n, int nrhs_) : pool(n * (size_t)nrhs_), stride(n), nrhs(nrhs_) {}
-  Batch get() { return Batch(pool.get(), stride, nrhs); }
+  BatchPoolT(size_t n, int nrhs_) : pool((n * (size_t)nrhs_ * sizeof(complex<T>) + sizeof(complex<double>) - 1) / sizeof(complex<double>)), stride(n), nrhs(nrhs_) {}
+  BatchT<T> get() { return BatchT<T>(reinterpret_cast<complex<T>*>(pool.get()), stride, nrhs); }
 };
+typedef BatchPoolT<double> BatchPool;
 
 typedef std::vector<complex<double>> cvec;
 
-inline void bblas(int op, const cvec* a, const cvec* b, const Batch* x, const Batch* y, Batch z, size_t n, unsigned mask) {
+template <typename T>
+inline void bblas(int op, const cvec* a, const cvec* b, const BatchT<T>* x, const BatchT<T>* y, BatchT<T> z, size_t n, unsigned mask) {
   std::vector<double> fa, fb;
   if (a) { fa.resize(2 * z.nrhs); for (int k = 0; k < z.nrhs; k++) { fa[2 * k] = (*a)[k].real(); fa[2 * k + 1] = (*a)[k].imag(); } }
   if (b) { fb.resize(2 * z.nrhs); for (int k = 0; k < z.nrhs; k++) { fb[2 * k] = (*b)[k].real(); fb[2 * k + 1] = (*b)[k].imag(); } }
-  ok(qmg_batch_blas(op, a ? fa.data() : 0, b ? fb.data() : 0, x ? x->p : 0, y ? y->p : 0, z.p, n, z.nrhs, z.stride, mask, current_stream()), "qmg_batch_blas");
+  ok(qmg_batch_blas_t(dtype_of<T>::value, op, a ? fa.data() : 0, b ? fb.data() : 0, x ? x->p : 0, y ? y->p : 0, z.p, n, z.nrhs, z.stride, mask, current_stream()), "qmg_batch_blas");
 }
-inline void bzero(Batch z, size_t n, unsigned mask) { bblas(QMG_BOP_ZERO, 0, 0, 0, 0, z, n, mask); }
-inline void bcopy(Batch z, Batch x, size_t n, unsigned mask) { bblas(QMG_BOP_COPY, 0, 0, &x, 0, z, n, mask); }
-inline void bcaxpy(const cvec& a, Batch x, Batch y, size_t n, unsigned mask) { bblas(QMG_BOP_CAXPY, &a, 0, &x, 0, y, n, mask); }   // y += a x
-inline void bcxpy(Batch x, Batch y, size_t n, unsigned mask) { bblas(QMG_BOP_CXPY, 0, 0, &x, 0, y, n, mask); }                   // y += x
-inline void bcaxpbyz(const cvec& a, Batch x, const cvec& b, Batch y, Batch z, size_t n, unsigned mask) { bblas(QMG_BOP_CAXPBYZ, &a, &b, &x, &y, z, n, mask); }
-inline void bxmyz(Batch x, Batch y, Batch z, size_t n, unsigned mask) {   // z = x - y
+template <typename T> inline void bzero(BatchT<T> z, size_t n, unsigned mask) { bblas<T>(QMG_BOP_ZERO, 0, 0, 0, 0, z, n, mask); }
+template <typename T> inline void bcopy(BatchT<T> z, BatchT<T> x, size_t n, unsigned mask) { bblas<T>(QMG_BOP_COPY, 0, 0, &x, 0, z, n, mask); }
+template <typename T> inline void bcaxpy(const cvec& a, BatchT<T> x, BatchT<T> y, size_t n, unsigned mask) { bblas<T>(QMG_BOP_CAXPY, &a, 0, &x, 0, y, n, mask); }   // y += a x
+template <typename T> inline void bcxpy(BatchT<T> x, BatchT<T> y, size_t n, unsigned mask) { bblas<T>(QMG_BOP_CXPY, 0, 0, &x, 0, y, n, mask); }                   // y += x
+template <typename T> inline void bcaxpbyz(const cvec& a, BatchT<T> x, const cvec& b, BatchT<T> y, BatchT<T> z, size_t n, unsigned mask) { bblas<T>(QMG_BOP_CAXPBYZ, &a, &b, &x, &y, z, n, mask); }
+template <typename T> inline void bxmyz(BatchT<T> x, BatchT<T> y, BatchT<T> z, size_t n, unsigned mask) {   // z = x - y
   const cvec one(z.nrhs, 1.0), mone(z.nrhs, -1.0);
   bcaxpbyz(one, x, mone, y, z, n, mask);
 }
-inline void bcxpyz(Batch x, Batch y, Batch z, size_t n, unsigned mask) {   // z = x + y
+template <typename T> inline void bcxpyz(BatchT<T> x, BatchT<T> y, BatchT<T> z, size_t n, unsigned mask) {   // z = x + y
   const cvec one(z.nrhs, 1.0);
   bcaxpbyz(one, x, one, y, z, n, mask);
 }
 
 // per-system |x_k|^2; entries of frozen systems keep `fill`
-inline std::vector<double> bnorm2sq(Batch x, size_t n, unsigned mask, double fill = 0.0) {
+template <typename T>
+inline std::vector<double> bnorm2sq(BatchT<T> x, size_t n, unsigned mask, double fill = 0.0) {
   std::vector<double> raw(2 * x.nrhs, 0.0), out(x.nrhs, fill);
-  ok(qmg_batch_reduce(QMG_BRED_NORM2, x.p, 0, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
+  ok(qmg_batch_reduce_t(dtype_of<T>::value, QMG_BRED_NORM2, x.p, 0, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
   for (int k = 0; k < x.nrhs; k++) if (is_active(mask, k)) out[k] = raw[2 * k];
   return out;
 }
-inline std::vector<double> bdiffnorm2sq(Batch x, Batch y, size_t n, unsigned mask) {
+template <typename T>
+inline std::vector<double> bdiffnorm2sq(BatchT<T> x, BatchT<T> y, size_t n, unsigned mask) {
   std::vector<double> raw(2 * x.nrhs, 0.0), out(x.nrhs, 0.0);
-  ok(qmg_batch_reduce(QMG_BRED_DIFFNORM2, x.p, y.p, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
+  ok(qmg_batch_reduce_t(dtype_of<T>::value, QMG_BRED_DIFFNORM2, x.p, y.p, n, x.nrhs, x.stride, mask, raw.data(), current_stream()), "qmg_batch_reduce");
   for (int k = 0; k < x.nrhs; k++) if (is_active(mask, k)) out[k] = raw[2 * k];
   return out;
 }
 // d[k][j] = <xs[j]_k, y_k>
-inline std::vector<cvec> bmultidot(const std::vector<Batch>& xs, int nj, Batch y, size_t n, unsigned mask) {
+template <typename T>
+inline std::vector<cvec> bmultidot(const std::vector<BatchT<T> >& xs, int nj, BatchT<T> y, size_t n, unsigned mask) {
   std::vector<cvec> out(y.nrhs, cvec(nj, 0.0));
   int done = 0;
   while (done < nj) {   // the ABI takes up to 32 vector sets per call
@@ -98,7 +117,7 @@ inline std::vector<cvec> bmultidot(const std::vector<Batch>& xs, int nj, Batch y
     std::vector<const void*> ptrs(jj);
     for (int j = 0; j < jj; j++) ptrs[j] = xs[done + j].p;
     std::vector<double> raw((size_t)2 * y.nrhs * jj, 0.0);
-    ok(qmg_batch_multidot(ptrs.data(), jj, y.p, n, y.nrhs, y.stride, mask, raw.data(), current_stream()), "qmg_batch_multidot");
+    ok(qmg_batch_multidot_t(dtype_of<T>::value, ptrs.data(), jj, y.p, n, y.nrhs, y.stride, mask, raw.data(), current_stream()), "qmg_batch_multidot");
     for (int k = 0; k < y.nrhs; k++)
       if (is_active(mask, k))
         for (int j = 0; j < jj; j++) out[k][done + j] = complex<double>(raw[((size_t)k * jj + j) * 2], raw[((size_t)k * jj + j) * 2 + 1]);
@@ -107,7 +126,8 @@ inline std::vector<cvec> bmultidot(const std::vector<Batch>& xs, int nj, Batch y
   return out;
 }
 // y_k += sum_j c[k][j] xs[j]_k
-inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<Batch>& xs, int nj, Batch y, size_t n, unsigned mask) {
+template <typename T>
+inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<BatchT<T> >& xs, int nj, BatchT<T> y, size_t n, unsigned mask) {
   if (nj <= 0) return;
   std::vector<double> cf((size_t)2 * nj * y.nrhs, 0.0);
   std::vector<const void*> ptrs(nj);
@@ -115,7 +135,13 @@ inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<Batch>& x
     ptrs[j] = xs[j].p;
     for (int k = 0; k < y.nrhs; k++) { cf[((size_t)j * y.nrhs + k) * 2] = c[k][j].real(); cf[((size_t)j * y.nrhs + k) * 2 + 1] = c[k][j].imag(); }
   }
-  ok(qmg_batch_multi_caxpy(cf.data(), ptrs.data(), nj, y.p, n, y.nrhs, y.stride, mask, current_stream()), "qmg_batch_multi_caxpy");
+  ok(qmg_batch_multi_caxpy_t(dtype_of<T>::value, cf.data(), ptrs.data(), nj, y.p, n, y.nrhs, y.stride, mask, current_stream()), "qmg_batch_multi_caxpy");
+}
+// z_k = x_k across storage precisions (round / widen), active systems only
+template <typename TD, typename TS>
+inline void bconvert(BatchT<TD> z, BatchT<TS> x, size_t n, unsigned mask) {
+  for (int k = 0; k < z.nrhs; k++)
+    if (is_active(mask, k)) ok(qmg_convert(z.vec(k), dtype_of<TD>::value, x.vec(k), dtype_of<TS>::value, n, current_stream()), "qmg_convert");
 }
 
 }  // namespace qmg
@@ -145,8 +171,10 @@ inline int batch_systems_that_fit(StatefulMultigridMG* mg, int outer_basis, int 
 }  // namespace qmg
 
 // lhs_k = A rhs_k for the active systems
-typedef void (*batch_matrix_op)(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data);
-typedef void (*batch_precond_op)(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb);
+template <typename T> using batch_matrix_op_t = void (*)(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask, void* extra_data);
+template <typename T> using batch_precond_op_t = void (*)(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb);
+typedef batch_matrix_op_t<double> batch_matrix_op;
+typedef batch_precond_op_t<double> batch_precond_op;
 
 inline void apply_stencil_2D_M_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data) {
   ((Stencil2D*)extra_data)->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
@@ -159,43 +187,51 @@ struct BatchOp {
   BatchOp(Stencil2D* st_, QMGStencilType type_) : st(st_), type(type_) {}
   static bool supported(QMGStencilType t) { return t == QMG_MATVEC_ORIGINAL || t == QMG_MATVEC_RIGHT_SCHUR; }
 };
-inline qmg::Batch batch_odd_half(qmg::Batch v, size_t half) { return qmg::Batch(v.p + half, v.stride, v.nrhs); }
+template <typename T> inline qmg::BatchT<T> batch_odd_half(qmg::BatchT<T> v, size_t half) { return qmg::BatchT<T>(v.p + half, v.stride, v.nrhs); }
 
 // lhs_e = rhs_e - D'_eo D'_oe rhs_e (apply_M_rbjacobi_schur, :1886-1908); only the even halves are read / written
-inline void apply_M_rbjacobi_schur_batch(Stencil2D* st, qmg::Batch lhs, qmg::Batch rhs, unsigned mask) {
+template <typename T>
+inline void apply_M_rbjacobi_schur_batch(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
   if (!st->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi_schur, but the rbjacobi stencil has not been allocated.\n"; return; }
   const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
-  qmg::BatchPool pool(lhs.stride, lhs.nrhs);
-  qmg::Batch t = pool.get();
-  const complex<double>* rh = st->rbjacobi_hopping_in_use();
-  st->launch_batch(QMG_P_OE | QMG_P_ZERO_O, t.p, rhs.p, 0, rh, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
-  st->launch_batch(QMG_P_EO | QMG_P_ZERO_E, t.p, t.p, 0, rh, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  qmg::BatchPoolT<T> pool(lhs.stride, lhs.nrhs);
+  qmg::BatchT<T> t = pool.get();
+  st->launch_set_batch<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, rhs.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  st->launch_set_batch<T>(QMG_P_EO | QMG_P_ZERO_E, t.p, t.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
   qmg::bxmyz(rhs, t, lhs, half, mask);
 }
-inline void apply_stencil_typed_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned mask, void* extra_data) {
+// lhs_k = M rhs_k (ORIGINAL operator: clover + hopping + shifts), one read of the matrices for the batch
+template <typename T>
+inline void apply_M_overwrite_batch_t(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  st->launch_set_batch<T>(QMG_P_ALL | QMG_P_ZERO, lhs.p, rhs.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, lhs.nrhs, lhs.stride, mask);
+}
+template <typename T>
+inline void apply_stencil_typed_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask, void* extra_data) {
   BatchOp* op = (BatchOp*)extra_data;
-  if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch(op->st, lhs, rhs, mask);
-  else op->st->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
+  if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch<T>(op->st, lhs, rhs, mask);
+  else apply_M_overwrite_batch_t<T>(op->st, lhs, rhs, mask);
 }
 // b_prep = prepare_M(b) (stencil_2d.h:2455-2490), b_prep OVERWRITTEN over the full vector
-inline void prepare_M_batch(Stencil2D* st, QMGStencilType type, qmg::Batch b_prep, qmg::Batch b, unsigned mask) {
+template <typename T>
+inline void prepare_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<T> b_prep, qmg::BatchT<T> b, unsigned mask) {
   const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
   if (type == QMG_MATVEC_RIGHT_SCHUR) {   // b_e - D'_eo b_o on the even half, zero on the odd half (:1912-1928)
-    st->launch_batch(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, 0, st->rbjacobi_hopping_in_use(), 0.0, 0.0, 0.0, b.nrhs, b.stride, mask);
+    st->launch_set_batch<T>(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, b.nrhs, b.stride, mask);
     qmg::bxmyz(b, b_prep, b_prep, half, mask);
     qmg::bzero(batch_odd_half(b_prep, half), cv - half, mask);
   } else qmg::bcopy(b_prep, b, cv, mask);
 }
 // x = reconstruct_M(y, b) (:2492-2527), x OVERWRITTEN
-inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::Batch x, qmg::Batch y, qmg::Batch b, unsigned mask) {
+template <typename T>
+inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<T> x, qmg::BatchT<T> y, qmg::BatchT<T> b, unsigned mask) {
   const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
   if (type == QMG_MATVEC_RIGHT_SCHUR) {   // (:1932-1957) t_o = b_o - D'_oe y_e ; t_e = y_e ; x = C^-1 t
-    qmg::BatchPool pool(x.stride, x.nrhs);
-    qmg::Batch t = pool.get();
-    st->launch_batch(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, 0, st->rbjacobi_hopping_in_use(), 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+    qmg::BatchPoolT<T> pool(x.stride, x.nrhs);
+    qmg::BatchT<T> t = pool.get();
+    st->launch_set_batch<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
     qmg::bxmyz(batch_odd_half(b, half), batch_odd_half(t, half), batch_odd_half(t, half), cv - half, mask);
     qmg::bcopy(t, y, half, mask);
-    st->launch_batch(QMG_P_CLOVER | QMG_P_ZERO, x.p, t.p, st->rbjacobi_cinv, 0, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+    st->launch_set_batch<T>(QMG_P_CLOVER | QMG_P_ZERO, x.p, t.p, Stencil2D::QMG_ARR_RBJ_CINV, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
   } else qmg::bcopy(x, y, cv, mask);
 }
 
@@ -203,12 +239,13 @@ inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::Batch x
 // MR(omega) for a batch: minv_vector_minres of krylov.hpp per system, in lock step.  x0 = 0 is REQUIRED (every use in the
 // K-cycle; the caller has zeroed phi): r0 = b.
 // ---------------------------------------------------------------------------------------------
-inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi, qmg::Batch phi0, int size, int max_iter, double eps, double omega,
-                                                                   batch_matrix_op matrix_vector, void* extra_info, unsigned mask) {
+template <typename T>
+inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::BatchT<T> phi, qmg::BatchT<T> phi0, int size, int max_iter, double eps, double omega,
+                                                                   batch_matrix_op_t<T> matrix_vector, void* extra_info, unsigned mask) {
   const int nrhs = phi.nrhs;
   std::vector<inversion_info> inv(nrhs);
-  qmg::BatchPool pool(phi.stride, nrhs);
-  qmg::Batch r = pool.get(), p = pool.get();
+  qmg::BatchPoolT<T> pool(phi.stride, nrhs);
+  qmg::BatchT<T> r = pool.get(), p = pool.get();
   const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
   qmg::bcopy(r, phi0, size, mask);
   std::vector<double> rsq = bsq, rsq_ref = bsq, bnorm(nrhs);
@@ -221,7 +258,7 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi
     conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < eps * bnorm[k]);
     if (!conv[k] && max_iter > 0) act |= 1u << k;
   }
-  std::vector<qmg::Batch> rp(2);
+  std::vector<qmg::BatchT<T> > rp(2);
   rp[0] = r; rp[1] = p;
   while (act) {
     matrix_vector(p, r, act, extra_info);
@@ -265,8 +302,9 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::Batch phi
 // together, so the basis index kb (and with it the restart points) is common; everything else is per system.
 // zero_guess: the caller has zeroed phi, r0 = b (krylov.hpp ZeroGuess).
 // ---------------------------------------------------------------------------------------------
-inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, int size, int max_iter, double eps, int restart_freq,
-                                             batch_matrix_op matrix_vector, void* extra_info, batch_precond_op precond, void* precond_info,
+template <typename T>
+inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> phi0, int size, int max_iter, double eps, int restart_freq,
+                                             batch_matrix_op_t<T> matrix_vector, void* extra_info, batch_precond_op_t<T> precond, void* precond_info,
                                              unsigned mask, bool zero_guess, inversion_verbose_struct* verb, const char* name,
                                              const std::vector<double>* eps_per_system = 0) {
   const int nrhs = phi.nrhs;
@@ -274,11 +312,11 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
   std::vector<double> epsv(nrhs, eps);   // relative tolerance per system (the K-cycle's inner tolerance depends on the system)
   if (eps_per_system) epsv = *eps_per_system;
   const int basis_max = (restart_freq > 0) ? restart_freq : max_iter;
-  qmg::BatchPool pool(phi.stride, nrhs);
-  qmg::Batch r = pool.get(), tmp = pool.get();
-  std::vector<qmg::Batch> Z, W;             // raw search directions and orthogonalised images (krylov.hpp: z is not orthogonalised)
-  std::vector<std::vector<double>> Wnorm2;   // [basis index][system]
-  std::vector<std::vector<qmg::cvec>> C(nrhs);   // C[system][k][i]: Gram-Schmidt coefficients of this cycle
+  qmg::BatchPoolT<T> pool(phi.stride, nrhs);
+  qmg::BatchT<T> r = pool.get(), tmp = pool.get();
+  std::vector<qmg::BatchT<T> > Z, W;        // raw search directions and orthogonalised images (krylov.hpp: z is not orthogonalised)
+  std::vector<std::vector<double> > Wnorm2;   // [basis index][system]
+  std::vector<std::vector<qmg::cvec> > C(nrhs);   // C[system][k][i]: Gram-Schmidt coefficients of this cycle
   std::vector<qmg::cvec> alphas(nrhs);           // alphas[system][k]
   std::vector<int> used(nrhs, 0);                // directions system k has taken in this cycle
   auto flush_x = [&]() {                         // x_k += sum_j y_kj z_j for every system with pending directions
@@ -317,11 +355,11 @@ inline std::vector<inversion_info> bgcr_core(qmg::Batch phi, qmg::Batch phi0, in
   int kb = 0;
   inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
   if (verb) { pverb.precond_verbosity = verb->precond_verbosity; pverb.precond_verb_prefix = verb->precond_verb_prefix; }
-  std::vector<qmg::Batch> rw(2);
+  std::vector<qmg::BatchT<T> > rw(2);
   while (act) {
     if (kb == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(std::vector<double>(nrhs, 0.0)); }
     for (int k = 0; k < nrhs; k++) { if ((int)C[k].size() <= kb) { C[k].push_back(qmg::cvec()); alphas[k].push_back(0.0); } }
-    qmg::Batch z = Z[kb], w = W[kb];
+    qmg::BatchT<T> z = Z[kb], w = W[kb];
     if (z.p == 0 || w.p == 0 || r.p == 0 || tmp.p == 0) {   // out of HBM: stop, report every active system as not converged
       std::cout << "[QMG-ERROR]: " << name << ": could not allocate basis vector " << kb << " for a batch of " << nrhs << " systems; size the batch with qmg::batch_systems_that_fit.\n";
       break;
@@ -409,9 +447,18 @@ struct BatchKcycle {
     }
     return BatchOp::supported(mg->get_coarsest_solve()->coarsest_stencil_app);
   }
+  // complex<float> shadows of every level's matrices and null vectors, for the QMG_C32 K-cycle (the fp64 hierarchy stays
+  // the master copy; call again after the hierarchy changes)
+  bool enable_f32_hierarchy() {
+    const int nl = mg->get_num_levels();
+    for (int i = 0; i < nl; i++) if (!mg->get_stencil(i) || !mg->get_stencil(i)->enable_f32_shadow()) return false;
+    for (int i = 0; i < nl - 1; i++) if (!mg->get_transfer(i)->enable_f32_shadow()) return false;
+    return true;
+  }
 };
 
-inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb) {
+template <typename T>
+inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb) {
   BatchKcycle* bk = (BatchKcycle*)extra_data;
   StatefulMultigridMG* mg = bk->mg;
   const int nrhs = bk->nrhs;
@@ -449,8 +496,8 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   const size_t coarse_size_solve = (coarse_type == QMG_MATVEC_RIGHT_SCHUR) ? coarse_size / 2 : coarse_size;
 
   // scratch for this level (recycled through VecPool's per-length free lists)
-  qmg::BatchPool fpool(fine_size, nrhs), cpool(coarse_size, nrhs);
-  qmg::Batch Atmp = fpool.get(), z1 = fpool.get(), r1 = fpool.get();
+  qmg::BatchPoolT<T> fpool(fine_size, nrhs), cpool(coarse_size, nrhs);
+  qmg::BatchT<T> Atmp = fpool.get(), z1 = fpool.get(), r1 = fpool.get();
   auto count = [&](QMGDslashType type, const std::vector<inversion_info>& inv, int lvl) {
     for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) mg->add_tracker_count(type, inv[k].ops_count, lvl);
   };
@@ -460,10 +507,10 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   // ---- 1. pre-smooth: A z1 ~ rhs, r1 = rhs - A z1
   qmg::bzero(z1, fine_size, mask);
   if (level_solve->pre_iters > 0) {
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z1, rhs, (int)fine_size_solve, level_solve->pre_iters, level_solve->pre_tol, 0.85,
-                                                                      apply_stencil_typed_batch, (void*)&fine_op, mask);
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z1, rhs, (int)fine_size_solve, level_solve->pre_iters, level_solve->pre_tol, 0.85,
+                                                                         apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
     count(QMG_DSLASH_TYPE_PRESMOOTH, inv, level);
-    apply_stencil_typed_batch(Atmp, z1, mask, (void*)&fine_op);
+    apply_stencil_typed_batch<T>(Atmp, z1, mask, (void*)&fine_op);
     mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
     qmg::bxmyz(rhs, Atmp, r1, fine_size_solve, mask);
   } else {
@@ -474,14 +521,14 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   if (fine_type == QMG_MATVEC_RIGHT_SCHUR) qmg::bzero(batch_odd_half(r1, fine_size_solve), fine_size - fine_size_solve, mask);
 
   // ---- 2. restrict, prepare, coarse solve (recursion = the "K"), reconstruct
-  qmg::Batch r_coarse = cpool.get(), r_coarse_prep = cpool.get(), e_coarse = cpool.get(), e_rec = cpool.get();
+  qmg::BatchT<T> r_coarse = cpool.get(), r_coarse_prep = cpool.get(), e_coarse = cpool.get(), e_rec = cpool.get();
   qmg::bzero(r_coarse, coarse_size, mask);
-  transfer->restrict_f2c_batch(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
+  transfer->restrict_f2c_batch_t<T>(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
   std::vector<double> inner_tol(nrhs, coarse_tol);
   if (coarse_type == QMG_MATVEC_ORIGINAL) qmg::bcopy(r_coarse_prep, r_coarse, coarse_size, mask);   // prepare_M is a copy; rnorm_prep == rnorm
   else {
     const std::vector<double> rn = qmg::bnorm2sq(r_coarse, coarse_size, mask);
-    prepare_M_batch(coarse_stencil, coarse_type, r_coarse_prep, r_coarse, mask);
+    prepare_M_batch<T>(coarse_stencil, coarse_type, r_coarse_prep, r_coarse, mask);
     const std::vector<double> rp = qmg::bnorm2sq(r_coarse_prep, coarse_size, mask);
     for (int k = 0; k < nrhs; k++)
       if (qmg::is_active(mask, k) && rp[k] > 0.0) inner_tol[k] = coarse_tol * std::sqrt(rn[k]) / std::sqrt(rp[k]);
@@ -489,36 +536,54 @@ inline void mg_preconditioner_batch(qmg::Batch lhs, qmg::Batch rhs, int size, un
   qmg::bzero(e_coarse, coarse_size, mask);
   std::vector<inversion_info> cinv;
   if (level == total_num_levels - 2) {
-    cinv = bgcr_core(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch, (void*)&coarse_op, 0, 0,
-                     mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart", &inner_tol);
+    cinv = bgcr_core<T>(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch<T>, (void*)&coarse_op,
+                        (batch_precond_op_t<T>)0, 0, mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart", &inner_tol);
   } else {
     mg->go_coarser();
-    cinv = bgcr_core(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch, (void*)&coarse_op,
-                     mg_preconditioner_batch, (void*)bk, mask, true, &verb2, coarse_restart == -1 ? "VPGCR" : "VPGCR-restart", &inner_tol);
+    cinv = bgcr_core<T>(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch<T>, (void*)&coarse_op,
+                        mg_preconditioner_batch<T>, (void*)bk, mask, true, &verb2, coarse_restart == -1 ? "VPGCR" : "VPGCR-restart", &inner_tol);
     mg->go_finer();
   }
   for (int k = 0; k < nrhs; k++)
     if (qmg::is_active(mask, k)) { mg->add_tracker_count(QMG_DSLASH_TYPE_KRYLOV, cinv[k].ops_count, level + 1); mg->add_iterations_count(cinv[k].iter, level + 1); }
-  reconstruct_M_batch(coarse_stencil, coarse_type, e_rec, e_coarse, r_coarse, mask);
+  reconstruct_M_batch<T>(coarse_stencil, coarse_type, e_rec, e_coarse, r_coarse, mask);
 
   // ---- 3. prolong and correct: lhs = z1 + P e
-  qmg::Batch z2 = r1;   // r1 is free again
+  qmg::BatchT<T> z2 = r1;   // r1 is free again
   qmg::bzero(z2, fine_size, mask);
-  transfer->prolong_c2f_batch(e_rec.p, e_rec.stride, z2.p, z2.stride, nrhs, mask);
+  transfer->prolong_c2f_batch_t<T>(e_rec.p, e_rec.stride, z2.p, z2.stride, nrhs, mask);
   if (coarse_type == QMG_MATVEC_RIGHT_SCHUR) qmg::bzero(batch_odd_half(z2, fine_size / 2), fine_size - fine_size / 2, mask);   // as multigrid.hpp
   qmg::bcxpyz(z1, z2, lhs, fine_size_solve, mask);
 
   // ---- 4. post-smooth on r2 = rhs - A lhs
   if (level_solve->post_iters > 0) {
-    apply_stencil_typed_batch(Atmp, lhs, mask, (void*)&fine_op);
-    qmg::Batch r2 = z2, z3 = z1;   // both free again
+    apply_stencil_typed_batch<T>(Atmp, lhs, mask, (void*)&fine_op);
+    qmg::BatchT<T> r2 = z2, z3 = z1;   // both free again
     qmg::bxmyz(rhs, Atmp, r2, fine_size_solve, mask);
     qmg::bzero(z3, fine_size, mask);
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
-                                                                      apply_stencil_typed_batch, (void*)&fine_op, mask);
+    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
+                                                                         apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
     count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
     qmg::bcxpy(z3, lhs, fine_size_solve, mask);
   }
+}
+
+// The fp32 K-cycle as the preconditioner of an fp64 flexible outer solve (BASELINE configs[4] "fp32"): the residual of
+// the active systems is rounded to complex<float>, ONE K-cycle runs entirely on the fp32 shadow hierarchy
+// (BatchKcycle::enable_f32_hierarchy), and the correction is widened back.  The outer VPGCR orthogonalises and
+// measures in fp64, so the solve converges to its fp64 tolerance; only the preconditioner's quality is fp32.
+// extra_data: BatchKcycle, as for mg_preconditioner_batch.
+inline void mg_preconditioner_batch_mixed(qmg::Batch lhs, qmg::Batch rhs, int size, unsigned mask, void* extra_data, inversion_verbose_struct* verb) {
+  BatchKcycle* bk = (BatchKcycle*)extra_data;
+  const size_t n = (size_t)bk->mg->get_lattice(bk->mg->get_multigrid_level())->get_size_cv_l();
+  qmg::BatchPoolT<float> pool(n, lhs.nrhs);
+  qmg::BatchT<float> r32 = pool.get(), z32 = pool.get();
+  if (r32.p == 0 || z32.p == 0) { std::cout << "[QMG-ERROR]: out of device memory for the fp32 residual / correction\n"; return; }
+  qmg::bzero(r32, n, mask);                       // (Schur: the odd half beyond `size` must be defined)
+  qmg::bconvert(r32, rhs, (size_t)size, mask);
+  qmg::bzero(z32, n, mask);
+  mg_preconditioner_batch<float>(z32, r32, size, mask, extra_data, verb);
+  qmg::bconvert(lhs, z32, (size_t)size, mask);
 }
 
 #endif

@@ -93,6 +93,12 @@ struct Stencil2D {
   void* clover32;
   void* hopping32;
 
+  // fp32 shadow (qmg_dtype QMG_C32; not in the reference, which is fp64 only): complex<float> copies of the arrays a
+  // K-cycle level streams -- the ORIGINAL clover / hopping and, when built, the right-block-Jacobi hopping and cinv.
+  // The fp64 arrays stay the master copy; enable_f32_shadow() (re)creates the copies from their current contents.
+  struct F32Shadow { void* clover; void* hopping; void* rbj_hopping; void* rbj_cinv; bool on; } f32;
+  enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2 };
+
   bool built_dagger;
   complex<double>*dagger_clover, *dagger_hopping, *dagger_twolink, *dagger_corner;
   bool built_rbjacobi;
@@ -122,6 +128,7 @@ struct Stencil2D {
     extra_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
     eo_cvector = 0;
     f32_matrices = false; clover32 = hopping32 = 0;
+    f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
     built_rbj_dagger = false; rbj_dagger_clover = rbj_dagger_hopping = rbj_dagger_twolink = rbj_dagger_corner = rbj_dagger_cinv = 0;
@@ -136,7 +143,29 @@ struct Stencil2D {
                                &rbj_dagger_clover, &rbj_dagger_hopping, &rbj_dagger_twolink, &rbj_dagger_corner, &rbj_dagger_cinv};
     for (auto p : all) if (*p != 0) deallocate_vector(p);
     disable_f32_matrices();
+    disable_f32_shadow();
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
+  }
+
+  bool enable_f32_shadow() {
+    disable_f32_shadow();
+    auto dup = [&](void** dst, const complex<double>* src, long n) -> bool {
+      if (src == 0) return true;
+      if (qmg_malloc(dst, (size_t)n * 8) != QMG_SUCCESS) { *dst = 0; return false; }
+      return qmg::ok(qmg_convert(*dst, QMG_C32, src, QMG_C64, (size_t)n, qmg::current_stream()), "qmg_convert");
+    };
+    // (a variant swapped in by perform_swap_* would be copied under the wrong name: shadows are taken in the unswapped state)
+    if (swap_dagger || swap_rbjacobi || swap_rbj_dagger) { std::cout << "[QMG-ERROR]: enable_f32_shadow called while a stencil variant is swapped in.\n"; return false; }
+    bool good = dup(&f32.clover, clover, lat->get_size_cm_l()) && dup(&f32.hopping, hopping, lat->get_size_hopping_l());
+    if (good && built_rbjacobi) good = dup(&f32.rbj_hopping, rbjacobi_hopping, lat->get_size_hopping_l()) && dup(&f32.rbj_cinv, rbjacobi_cinv, lat->get_size_cm_l());
+    if (!good) { disable_f32_shadow(); return false; }
+    f32.on = true;
+    return true;
+  }
+  void disable_f32_shadow() {
+    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv};
+    for (auto p : all) if (*p) { qmg_free(*p); *p = 0; }
+    f32.on = false;
   }
 
   // Opt-in storage format for operators that only PRECONDITION (a K-cycle inside a flexible fp64 outer solver): keep a
@@ -292,6 +321,34 @@ struct Stencil2D {
     qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
   }
   const complex<double>* rbjacobi_hopping_in_use() const { return swap_rbjacobi ? hopping : rbjacobi_hopping; }
+
+  // The one launch of the batch layer in either storage precision: pieces of the operator built from array set `set`
+  // (ORIGINAL: clover + hopping; RBJ_HOPPING: the right-block-Jacobi hopping alone; RBJ_CINV: cinv in the clover slot),
+  // applied to the active systems of a batch of complex<T> vectors.  T = float streams the fp32 shadow.
+  template <typename T>
+  void launch_set_batch(unsigned pieces, complex<T>* lhs, complex<T>* rhs, QMGArraySet set, complex<double> s, complex<double> es, complex<double> ds,
+                        int nrhs, size_t stride, unsigned mask) {
+    qmg_stencil_desc d;
+    d.Lx = lat->get_dim_mu(0); d.Ly = lat->get_dim_mu(1); d.nc = lat->get_nc();
+    d.shift[0] = s.real(); d.shift[1] = s.imag();
+    d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
+    d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (sizeof(T) == sizeof(float)) {
+      if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
+      d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
+      d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+      qmg::ok(qmg_stencil_apply_t(QMG_C32, &d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_t");
+      return;
+    }
+    d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
+    d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
+    if (set == QMG_ARR_ORIGINAL && f32_matrices) {   // opt-in fp32 STORAGE of the coarse matrices, fp64 vectors (enable_f32_matrices)
+      d.clover = clover32; d.hopping = hopping32;
+      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
+      return;
+    }
+    qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
+  }
 
   // lhs_k = M rhs_k for the active systems of a lock-step batch (<= 16 vectors `stride` apart): one read of the matrices;
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.

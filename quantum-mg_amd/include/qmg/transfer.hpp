@@ -28,6 +28,8 @@ class TransferMG {
   complex<double>* restrict_store;   // same for an asymmetric restrictor, or 0
   QMGDoublingType doubling;
   bool is_init;
+  void* null_store32;                // complex<float> shadow of null_store / restrict_store (enable_f32_shadow), or 0
+  void* restrict_store32;
 
   bool geometry_ok() {
     fine_sites_per_coarse = fine_lat->get_nc();
@@ -64,7 +66,7 @@ class TransferMG {
   TransferMG(Lattice2D* in_fine_lat, Lattice2D* in_coarse_lat, complex<double>** in_null_vectors, bool do_block_ortho = true,
              bool save_decomp = false, QMGDoublingType in_doubling = QMG_DOUBLE_NONE)
       : fine_lat(in_fine_lat), coarse_lat(in_coarse_lat), const_num_null_vec(in_coarse_lat->get_nc()), null_store(0), restrict_store(0),
-        doubling(in_doubling), is_init(false), null_vectors(0), restrict_null_vectors(0), block_cholesky(0), block_L(0), block_U(0) {
+        doubling(in_doubling), is_init(false), null_store32(0), restrict_store32(0), null_vectors(0), restrict_null_vectors(0), block_cholesky(0), block_L(0), block_U(0) {
     if (!geometry_ok()) return;
     null_store = copy_in(in_null_vectors);
     null_vectors = new complex<double>*[const_num_null_vec];
@@ -112,7 +114,27 @@ class TransferMG {
     if (block_cholesky) deallocate_vector(&block_cholesky);
     if (block_L) deallocate_vector(&block_L);
     if (block_U) deallocate_vector(&block_U);
+    disable_f32_shadow();
   }
+
+  // fp32 shadow of the (block-orthonormalised) null vectors for the QMG_C32 K-cycle; the fp64 vectors stay the master copy
+  bool enable_f32_shadow() {
+    disable_f32_shadow();
+    const size_t n = (size_t)const_num_null_vec * (size_t)fine_lat->get_size_cv_l();
+    if (qmg_malloc(&null_store32, n * 8) != QMG_SUCCESS) { null_store32 = 0; return false; }
+    bool good = qmg::ok(qmg_convert(null_store32, QMG_C32, null_store, QMG_C64, n, qmg::current_stream()), "qmg_convert");
+    if (good && restrict_store) {
+      if (qmg_malloc(&restrict_store32, n * 8) != QMG_SUCCESS) { restrict_store32 = 0; good = false; }
+      else good = qmg::ok(qmg_convert(restrict_store32, QMG_C32, restrict_store, QMG_C64, n, qmg::current_stream()), "qmg_convert");
+    }
+    if (!good) disable_f32_shadow();
+    return good;
+  }
+  void disable_f32_shadow() {
+    if (null_store32) { qmg_free(null_store32); null_store32 = 0; }
+    if (restrict_store32) { qmg_free(restrict_store32); restrict_store32 = 0; }
+  }
+  bool has_f32_shadow() const { return null_store32 != 0; }
 
   bool is_initialized() { return is_init; }
 
@@ -139,6 +161,26 @@ class TransferMG {
     qmg::ok(qmg_restrict_batch(restrict_store ? restrict_store : null_store, const_num_null_vec, fine, coarse, fine_lat->get_dim_mu(0),
                                fine_lat->get_dim_mu(1), fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(),
                                nrhs, fstride, cstride, mask, qmg::current_stream()), "qmg_restrict_batch");
+  }
+
+  // either storage precision (T = float: the fp32 shadow of the null vectors)
+  template <typename T>
+  void prolong_c2f_batch_t(complex<T>* coarse, size_t cstride, complex<T>* fine, size_t fstride, int nrhs, unsigned mask) {
+    const bool f = sizeof(T) == sizeof(float);
+    if (f && !null_store32) { std::cout << "[QMG-ERROR]: fp32 prolong without an fp32 shadow (TransferMG::enable_f32_shadow).\n"; return; }
+    qmg::ok(qmg_prolong_batch_t(f ? QMG_C32 : QMG_C64, f ? (const void*)null_store32 : (const void*)null_store, const_num_null_vec, coarse, fine,
+                                fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1),
+                                coarse_lat->get_nc(), nrhs, cstride, fstride, mask, qmg::current_stream()), "qmg_prolong_batch_t");
+  }
+  template <typename T>
+  void restrict_f2c_batch_t(complex<T>* fine, size_t fstride, complex<T>* coarse, size_t cstride, int nrhs, unsigned mask) {
+    const bool f = sizeof(T) == sizeof(float);
+    if (f && !null_store32) { std::cout << "[QMG-ERROR]: fp32 restrict without an fp32 shadow (TransferMG::enable_f32_shadow).\n"; return; }
+    const void* r64 = restrict_store ? restrict_store : null_store;
+    const void* r32 = restrict_store32 ? restrict_store32 : null_store32;
+    qmg::ok(qmg_restrict_batch_t(f ? QMG_C32 : QMG_C64, f ? r32 : r64, const_num_null_vec, fine, coarse, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1),
+                                 fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), nrhs, fstride, cstride, mask,
+                                 qmg::current_stream()), "qmg_restrict_batch_t");
   }
 
   bool is_symmetric() { return restrict_store == 0; }

@@ -20,11 +20,17 @@ def slot_range(total_rhs, rank, world):
     return (idx[0], idx[-1] + 1) if idx else (0, 0)
 
 
-def allgather_by_allreduce(buf, total_rhs, rank, world, dist):
+def allgather_by_allreduce(buf, total_rhs, rank, world, dist, own=None):
     """ONE sum all-reduce per global reduction step.  `buf` is a float64 tensor of total_rhs (x width) entries in
-    which this rank has filled only its own slots (others zero); afterwards every rank holds every entry, so all
-    ranks take the same convergence / restart decision in lock-step."""
+    which this rank has filled its own slots; afterwards every rank holds every entry, so all ranks take the same
+    convergence / restart decision in lock-step.  The slots a rank does not own must be ZERO when the sum is taken:
+    pass `own` = (first, one-past-last) index of this rank's slots to have every other slot cleared first -- a buffer
+    that is reused from step to step still holds the other ranks' values of the previous step, which would otherwise
+    be summed in again (world - 1 stale copies per step)."""
     if dist is not None and world > 1:
+        if own is not None:
+            buf[:own[0]].zero_()
+            buf[own[1]:].zero_()
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 

@@ -42,6 +42,25 @@ def main():
     want = torch.tensor([ol.norm2sq(ol.stencil_apply(d, rhs_vec(k))) for k in range(total_rhs)], dtype=torch.float64)
     assert torch.allclose(buf, want, rtol=1e-14), (buf, want)
 
+    # a REUSED buffer (bench.py StaggeredMultiRHS.step): after the first step the foreign slots hold last step's values;
+    # with `own` they are cleared before the sum, so every step returns exactly the fresh values (three steps here)
+    slots = torch.zeros(world * 2, dtype=torch.float64)
+    for step in range(3):
+        slots[2 * rank] = 10.0 * step + rank
+        slots[2 * rank + 1] = 100.0 * step + rank
+        sharding.allgather_by_allreduce(slots, world * 2, rank, world, dist, own=(2 * rank, 2 * rank + 2))
+        fresh = torch.tensor([v for r in range(world) for v in (10.0 * step + r, 100.0 * step + r)], dtype=torch.float64)
+        assert torch.equal(slots, fresh), (step, slots, fresh)
+
+    # the C-ABI's own rendezvous (qmg_comm_rendezvous: the TCP leg of qmg_comm_init_env, no GPU involved): rank 0's
+    # 128 bytes reach every rank
+    import ctypes as C
+    qmg = importlib.import_module("quantum-mg_amd")
+    os.environ["QMG_COMM_PORT"] = str(int(os.environ["MASTER_PORT"]) + 7)
+    blob = (C.c_ubyte * 128)(*([(7 * i + 3) % 251 for i in range(128)] if rank == 0 else [0] * 128))
+    assert qmg.lib().qmg_comm_rendezvous(blob, world, rank) == 0
+    assert list(blob) == [(7 * i + 3) % 251 for i in range(128)]
+
     # lock-step decision: identical on all ranks, true only when ALL rhs are below tolerance
     bn = torch.tensor([ol.norm2sq(rhs_vec(k)) for k in range(total_rhs)], dtype=torch.float64)
     res = bn * 1e-22

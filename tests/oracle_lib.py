@@ -254,3 +254,39 @@ def wilson_kcycle(L, mass, n_refine, coarse_dof, gauge, nullvecs, b, tol=1e-10, 
     it = lib().qo_wilson_kcycle(L, C.c_double(mass), n_refine, coarse_dof, _p(gauge), ptrs, _p(b), C.c_double(tol), max_iter, restart,
                                 C.c_double(inner_tol), C.c_double(coarsest_tol), n_smooth, _p(x), C.byref(true_res), ops, its)
     return it, x, true_res.value, list(ops), list(its)
+
+
+def wilson_kcycle_history(L, mass, n_refine, coarse_dof, gauge, nullvecs, b, tol=1e-10, max_iter=1000, restart=32, inner_tol=0.2,
+                          coarsest_tol=0.2, n_smooth=2):
+    """wilson_kcycle plus the outer relative-residual history and the iteration count of every coarsest solve
+    (negative = that solve hit its 1000-iteration cap)."""
+    ptrs = (C.c_void_p * n_refine)(*[nv.ctypes.data for nv in nullvecs])
+    x = cvec(L * L * 2)
+    true_res = C.c_double()
+    ops = (C.c_long * (n_refine + 1))()
+    its = (C.c_long * (n_refine + 1))()
+    nh, nch = max_iter + 8, 1 << 16
+    hist = np.zeros(nh)
+    chist = np.zeros(nch, dtype=np.int64)
+    nho, ncho = C.c_int(), C.c_int()
+    it = lib().qo_wilson_kcycle_history(L, C.c_double(mass), n_refine, coarse_dof, _p(gauge), ptrs, _p(b), C.c_double(tol), max_iter, restart,
+                                        C.c_double(inner_tol), C.c_double(coarsest_tol), n_smooth, _p(x), C.byref(true_res), ops, its,
+                                        hist.ctypes.data_as(C.POINTER(C.c_double)), nh, C.byref(nho), chist.ctypes.data_as(C.POINTER(C.c_long)), nch, C.byref(ncho))
+    return it, x, true_res.value, list(ops), list(its), hist[:nho.value].copy(), chist[:ncho.value].copy()
+
+
+KRYLOV_CG, KRYLOV_BICGSTAB_L, KRYLOV_RICHARDSON, KRYLOV_MR, KRYLOV_GCR = range(5)
+
+
+def krylov_solve(kind, desc, b, max_iter, tol, param_i=0, param_d=0.0, x0=None, dagger_desc=None, normal=False, nhist=0):
+    """CPU twins of the facade's Krylov drivers on a stencil operator (oracle/qmg_oracle_kcycle.cpp qo_krylov_solve).
+    Returns (converged, iterations, x, resSq, history)."""
+    n = desc.Lx * desc.Ly * desc.nc
+    x = cvec(n) if x0 is None else np.array(x0, dtype=np.complex128)
+    it, rsq = C.c_int(), C.c_double()
+    hist = np.zeros(max(nhist, 1))
+    rc = lib().qo_krylov_solve(kind, C.byref(desc), C.byref(dagger_desc) if dagger_desc is not None else None, 1 if normal else 0, _p(x), _p(b),
+                               max_iter, C.c_double(tol), param_i, C.c_double(param_d), C.byref(it), C.byref(rsq),
+                               hist.ctypes.data_as(C.POINTER(C.c_double)), nhist)
+    assert rc >= 0
+    return bool(rc), it.value, x, rsq.value, hist[:min(nhist, it.value)].copy()

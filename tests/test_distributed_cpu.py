@@ -33,3 +33,18 @@ def test_two_rank_gloo_worker():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_rendezvous_times_out_instead_of_hanging():
+    """A rank whose rank 0 never shows up gets an error after QMG_COMM_TIMEOUT_S, not a hang (the id-file
+    hand-shake could block forever on a stale file)."""
+    import ctypes as C
+    import time
+    qmg = importlib.import_module("quantum-mg_amd")
+    code = ("import importlib, ctypes as C, sys; q = importlib.import_module('quantum-mg_amd'); "
+            "b = (C.c_ubyte * 128)(); sys.exit(0 if q.lib().qmg_comm_rendezvous(b, 2, 1) != 0 else 1)")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", QMG_COMM_PORT="29599", QMG_COMM_TIMEOUT_S="2"),
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert time.time() - t0 < 30

@@ -181,3 +181,40 @@ def test_reductions():
     assert np.allclose(ol.norm2sq_cv_timeslice(a, L, L, nc), (np.abs(grid) ** 2).sum(axis=(0, 2)), rtol=1e-13)
     gb = cs.eo_to_grid(b, L, L, nc)
     assert np.allclose(ol.dot_cv_timeslice(a, b, L, L, nc), (np.conj(grid) * gb).sum(axis=(0, 2)), rtol=1e-13)
+
+
+def test_l128_fixture_is_past_critical_at_mass_minus_007(golden_dir):
+    """Evidence for profiles/r01_driver_sweep.log `n13_128_1_12 ... failed to converge`: on the reference's own 128^2
+    configuration (tests/common_cfgs_u1/l128t128b60_heatbath.dat) the Wilson operator at mass -0.07 has a NEGATIVE real
+    eigenvalue (-2.5e-4): this configuration's critical mass is -0.06975, inside the ensemble's -0.0706(15)
+    (tests/n15_wilson_goldstone_u1_heatbath/critical_mass.txt), so mass -0.07 is past critical and the Galerkin coarse
+    operator inherits an indefinite near-null mode on which restarted GCR(32) stagnates.  Computed with the independent
+    coordinate-space operator (tests/coordspace.py) and scipy's shift-invert Arnoldi -- no oracle, no HIP code."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    Lq = 128
+    ph = np.loadtxt(os.path.join(golden_dir, "l128t128b60_heatbath.dat"))
+    Ux, Uy = cs.phases_to_links(ph, Lq, Lq)
+    N = 2 * Lq * Lq
+    X, Y = [a.ravel() for a in np.meshgrid(np.arange(Lq), np.arange(Lq), indexing="ij")]
+    idx = lambda x, y, c: ((x % Lq) * Lq + (y % Lq)) * 2 + c
+    s1 = np.array([[0, 1], [1, 0]], dtype=complex)
+    s2 = np.array([[0, -1j], [1j, 0]])
+    rows, cols, vals = [], [], []
+    for r in range(2):
+        rows.append(idx(X, Y, r)); cols.append(idx(X, Y, r)); vals.append(np.full(Lq * Lq, 2.0 - 0.07, dtype=complex))
+    for mu, (U, sig) in enumerate(((Ux, s1), (Uy, s2))):
+        Hp, Hm = 0.5 * (-np.eye(2) + sig), 0.5 * (-np.eye(2) - sig)
+        dx, dy = (1, 0) if mu == 0 else (0, 1)
+        Uf, Ub = U[X, Y], np.conj(U[(X - dx) % Lq, (Y - dy) % Lq])
+        for r in range(2):
+            for c in range(2):
+                rows.append(idx(X, Y, r)); cols.append(idx(X + dx, Y + dy, c)); vals.append(Uf * Hp[r, c])
+                rows.append(idx(X, Y, r)); cols.append(idx(X - dx, Y - dy, c)); vals.append(Ub * Hm[r, c])
+    A = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+    v = cs.gaussian_cvec(N, 3).reshape(Lq, Lq, 2)
+    assert np.linalg.norm(A @ v.reshape(-1) - cs.wilson_apply(v, Ux, Uy, -0.07).reshape(-1)) < 1e-11 * np.linalg.norm(v)
+    ev = sla.eigs(A, k=4, sigma=0.0, which="LM", return_eigenvectors=False)
+    real_ev = np.sort(ev[np.abs(ev.imag) < 1e-9].real)
+    assert real_ev[0] < 0.0 and abs(real_ev[0] + 2.5315e-4) < 2e-6, real_ev      # past critical
+    assert real_ev[1] > 0.0                                                      # indefinite
