@@ -1108,9 +1108,13 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (g_stencil_rows > 0 && gy > (unsigned)g_stencil_rows) gy = (unsigned)g_stencil_rows;
   hipStream_t st = as_stream(stream);
 
-  if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && g_stencil_pair > 0 && lhs != rhs) {
+  // fp32: the one-site-per-lane-group kernel is the faster one (4096^2 Wilson: 0.573 ms against 0.592 ms for the paired
+  // kernel, profiles/r02_kernel_rooflines.json: half the bytes per site leave the paired kernel's longer dependent chain
+  // exposed), so the paired kernel serves fp64 only unless "stencil_pair" asks for it explicitly (>= 8)
+  const bool use_pair = vec32 ? (g_stencil_pair >= 8) : (g_stencil_pair > 0);
+  if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && use_pair && lhs != rhs) {
     const int E = (vec32 && nc % 2 == 0) ? nc * nc / 2 : nc * nc;   // lanes per site (KA<T, NC>::E)
-    const int rows = (g_stencil_pair >= 4 && d->Ly % 4 == 0) ? 4 : (g_stencil_pair >= 2 && d->Ly % 2 == 0) ? 2 : 1;
+    const int rows = ((g_stencil_pair & 7) >= 4 && d->Ly % 4 == 0) ? 4 : ((g_stencil_pair & 7) >= 2 && d->Ly % 2 == 0) ? 2 : 1;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
     unsigned gyp = (unsigned)(d->Ly / rows);
     if (gyp > 65535u) gyp = 65535u;

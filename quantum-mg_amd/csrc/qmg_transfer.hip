@@ -143,6 +143,22 @@ __global__ __launch_bounds__(BLOCK) void k_restrict_generic(const void* __restri
   }
 }
 
+// The (up to 8) systems of one pass, indexed by compile-time slot numbers only: a by-value struct indexed at run time
+// (BatchIdx::id[s0 + q]) is copied to scratch memory by the compiler.  Slots beyond `n` alias slot 0 (computed, discarded).
+struct PassIds { int n; int id[8]; };
+// run-time slot -> system id without indexing the struct (a chain of selects on registers)
+__device__ __forceinline__ int pick_id(const PassIds& p, int q) {
+  const int a = (q & 1) ? p.id[1] : p.id[0], b = (q & 1) ? p.id[3] : p.id[2], c = (q & 1) ? p.id[5] : p.id[4], d = (q & 1) ? p.id[7] : p.id[6];
+  const int ab = (q & 2) ? b : a, cd = (q & 2) ? d : c;
+  return (q & 4) ? cd : ab;
+}
+static PassIds make_pass(const BatchIdx& bi, int s0) {
+  PassIds p;
+  p.n = (bi.n - s0 < 8) ? bi.n - s0 : 8;
+  for (int q = 0; q < 8; q++) p.id[q] = bi.id[s0 + (q < p.n ? q : 0)];
+  return p;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Transfer for a lock-step batch (2..16 systems): the null vectors -- nvec of the (nvec + 2k) size_cv_f complex a call
 // moves, and the same for every system -- are streamed ONCE for up to KB systems.  Both kernels work on the fine elements
@@ -156,10 +172,10 @@ __global__ __launch_bounds__(BLOCK) void k_restrict_generic(const void* __restri
 // address-bound at 2 TB/s, profiles/r01_kernel_rooflines.json.)
 template <typename T, int KB>
 __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse, void* __restrict__ fine,
-                                                         const XferGeom g, const BatchIdx bi, int s0, long cstride, long fstride, int SX) {
+                                                         const XferGeom g, const PassIds ids, long cstride, long fstride, int SX) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* cl = reinterpret_cast<cplx*>(smem_raw);          // [SX][nvec * KB + 1]
-  const int ns = (bi.n - s0 < KB) ? bi.n - s0 : KB;
+  const int ns = (ids.n < KB) ? ids.n : KB;
   const int G = (g.bx / 2) * g.fnc, R = 2 * g.by;
   const int cLx = 2 * g.chr;
   const int cx0 = blockIdx.x * SX;
@@ -167,13 +183,13 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
   const int sstride = nvec * KB + 1;
   long fo[KB];
 #pragma unroll
-  for (int q = 0; q < KB; q++) fo[q] = (long)bi.id[s0 + ((q < ns) ? q : 0)] * fstride;   // unused slots alias slot 0 (computed, discarded)
+  for (int q = 0; q < KB; q++) fo[q] = (long)ids.id[q] * fstride;   // unused slots alias slot 0 (computed, discarded)
   for (int cy = blockIdx.y; cy < g.cLy; cy += gridDim.y) {
     __syncthreads();   // the previous tile's reads are done
     for (int t = threadIdx.x; t < nsx * KB * nvec; t += BLOCK) {   // d fastest: coalesced runs of nvec coarse values
       const int d = t % nvec, q = (t / nvec) % KB, s = t / (nvec * KB);
       const long ci = coarse_site_index(g, cx0 + s, cy);
-      cl[s * sstride + d * KB + q] = (q < ns) ? ldc<T>(coarse, (long)bi.id[s0 + q] * cstride + ci * g.cnc + d) : cmake(0.0, 0.0);
+      cl[s * sstride + d * KB + q] = (q < ns) ? ldc<T>(coarse, (long)pick_id(ids, q) * cstride + ci * g.cnc + d) : cmake(0.0, 0.0);
     }
     __syncthreads();
     const int row_w = nsx * G;
@@ -216,10 +232,10 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
 // for (d, system) = bit-reversed lane id: one writer per output, fixed order, deterministic.
 template <typename T, int KB>
 __global__ __launch_bounds__(BLOCK) void k_brestrict_tile(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine, void* __restrict__ coarse,
-                                                          const XferGeom g, const BatchIdx bi, int s0, long cstride, long fstride) {
+                                                          const XferGeom g, const PassIds ids, long cstride, long fstride) {
   constexpr int DC = 32 / KB;        // null vectors per pass
   constexpr int NV = 64;             // doubles per lane per pass: DC * KB complex
-  const int ns = (bi.n - s0 < KB) ? bi.n - s0 : KB;
+  const int ns = (ids.n < KB) ? ids.n : KB;
   const int cLx = 2 * g.chr;
   const long ncs = (long)cLx * g.cLy;
   const int G = (g.bx / 2) * g.fnc;
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_tile(const void* __restrict
   const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
   long fo[KB];
 #pragma unroll
-  for (int q = 0; q < KB; q++) fo[q] = (long)bi.id[s0 + ((q < ns) ? q : 0)] * fstride;
+  for (int q = 0; q < KB; q++) fo[q] = (long)ids.id[q] * fstride;
   // the (d, system) pair this lane ends up holding: bit-reversed lane id
   const int pair = ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4);
   const int my_dq = pair / KB, my_q = pair - my_dq * KB;
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_tile(const void* __restrict
         }
       }
       if (my_dq < dn && my_q < ns) {
-        const long o = (long)bi.id[s0 + my_q] * cstride + ci * g.cnc + d0 + my_dq;
+        const long o = (long)pick_id(ids, my_q) * cstride + ci * g.cnc + d0 + my_dq;
         const cplx c = ldc<T>(coarse, o);
         stc<T>(coarse, o, cmake(c.x + v[0], c.y + v[1]));
       }
@@ -348,6 +364,108 @@ static int make_geom(XferGeom* g, int fLx, int fLy, int fnc, int cLx, int cLy, i
   return QMG_SUCCESS;
 }
 
+// Restrict, blocks of at most 32 elements (the fine level: 4x4 blocks of nc = 2) and at most NVT null vectors: ONE element
+// per lane.  Phase 1 issues EVERY load of the site at once -- the KB fine values and all nvec null-vector entries of the
+// lane's element, NVT + KB 16-byte loads in flight per lane, which is what hides the HBM latency at two wavefronts per
+// SIMD -- and keeps them in registers.  Phase 2 runs nvec/DC passes out of registers: a pass forms DC = 16/KB null
+// vectors x KB systems of products (32 doubles) and halves them over the 32 lanes in 16+8+4+2+1 = 31 exchanges down to
+// ONE double per lane -- component (lane bit 4) of the sum for (d, system) = the bit-reversed low lane bits -- kept in a
+// register per pass.  Phase 3 adds the nvec/DC results into the coarse vector (independent read-modify-writes).  While
+// one wavefront of a SIMD computes, the other has its loads in flight.
+template <typename T, int KB, int NVT>
+__global__ __launch_bounds__(BLOCK) void k_brestrict_small(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine, void* __restrict__ coarse,
+                                                           const XferGeom g, const PassIds ids, long cstride, long fstride) {
+  typedef typename CStore<T>::type ct;
+  constexpr int DC = 16 / KB;        // null vectors per pass
+  constexpr int NV = 32;             // doubles per lane per pass
+  constexpr int NP = NVT / DC;       // passes
+  const int ns = (ids.n < KB) ? ids.n : KB;
+  const int cLx = 2 * g.chr;
+  const long ncs = (long)cLx * g.cLy;
+  const int G = (g.bx / 2) * g.fnc;
+  const int nel = 2 * g.by * G;      // <= 32
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+  // the value this lane ends up holding after the halving: index bits (b0 b1 b2 b3 b4) = lane bits 0..4, MSB first
+  const int idx = ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4);
+  const int my_pair = idx >> 1, my_comp = idx & 1;
+  const int my_dq = my_pair / KB, my_q = my_pair - my_dq * KB;
+  for (long cs = (long)blockIdx.x * (BLOCK / 32) + grp; cs < ncs; cs += (long)gridDim.x * (BLOCK / 32)) {
+    const int cy = (int)(cs / cLx), cx = (int)(cs - (long)cy * cLx);
+    const long ci = coarse_site_index(g, cx, cy);
+    const bool have = l < nel;
+    const int rr = have ? l / G : 0, el = have ? l - rr * G : 0;
+    const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
+    const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc + el;
+    // ---- phase 1: every load of this site
+    ct fr[KB], nr[NVT];
+    ct zero;
+    zero.x = 0; zero.y = 0;
+#pragma unroll
+    for (int q = 0; q < KB; q++) {   // (an explicit branch: `cond ? load : zero` on a struct becomes a select of ADDRESSES and a flat load from scratch)
+      fr[q] = zero;
+      if (have && q < ns) fr[q] = reinterpret_cast<const ct*>(fine)[(long)ids.id[q] * fstride + e];
+    }
+#pragma unroll
+    for (int d = 0; d < NVT; d++) {
+      if (have && d < nvec) {
+        if (sizeof(T) == 8) {
+          const ct* src = reinterpret_cast<const ct*>(nullv) + (long)d * g.fsize + e;
+          nr[d].x = __builtin_nontemporal_load(&src->x);
+          nr[d].y = __builtin_nontemporal_load(&src->y);
+        } else {   // ONE 8-byte load (two component loads would be two 4-byte instructions)
+          const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long*>(nullv) + (long)d * g.fsize + e);
+          nr[d].x = (T)__int_as_float((int)(raw & 0xFFFFFFFFll));
+          nr[d].y = (T)__int_as_float((int)(raw >> 32));
+        }
+      } else nr[d] = zero;
+    }
+    // ---- phase 2: products and recursive halving, out of registers
+    double res[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+      double v[NV];
+#pragma unroll
+      for (int dq = 0; dq < DC; dq++) {
+        const double nx = (double)nr[ps * DC + dq].x, ny = (double)nr[ps * DC + dq].y;
+#pragma unroll
+        for (int q = 0; q < KB; q++) {   // conj(nv) f
+          const double fx = (double)fr[q].x, fy = (double)fr[q].y;
+          v[(dq * KB + q) * 2] = fma(nx, fx, ny * fy);
+          v[(dq * KB + q) * 2 + 1] = fma(nx, fy, -ny * fx);
+        }
+      }
+#pragma unroll
+      for (int step = 0; step < 5; step++) {
+        const int m = 1 << step;
+        const int half = NV >> (step + 1);
+        const bool up = (l & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+          const double lo = v[i], hi = v[i + half];
+          const double send = up ? lo : hi;
+          const double keep = up ? hi : lo;
+          double recv;
+          if (m == 1) recv = lane_xor1(send);
+          else if (m == 2) recv = lane_xor2(send);
+          else recv = __shfl_xor(send, m);
+          v[i] = keep + recv;
+        }
+      }
+      res[ps] = v[0];
+    }
+    // ---- phase 3: one read-modify-write per pass (this lane's component of (d = ps*DC + my_dq, system my_q))
+    if (my_q < ns) {
+      T* out = reinterpret_cast<T*>(reinterpret_cast<ct*>(coarse) + (long)pick_id(ids, my_q) * cstride + ci * g.cnc) + my_comp;
+      T prev[NP];
+#pragma unroll
+      for (int ps = 0; ps < NP; ps++) prev[ps] = (ps * DC + my_dq < nvec) ? out[2 * (ps * DC + my_dq)] : (T)0;
+#pragma unroll
+      for (int ps = 0; ps < NP; ps++)
+        if (ps * DC + my_dq < nvec) out[2 * (ps * DC + my_dq)] = (T)((double)prev[ps] + res[ps]);
+    }
+  }
+}
+
 template <typename T>
 static int launch_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse, const XferGeom& g, hipStream_t st) {
   if ((g.bx & 1) == 0) {
@@ -408,9 +526,9 @@ static int prolong_batch_impl(const void* nullvecs, int nvec, const void* coarse
     const size_t smem = (size_t)SX * (nvec * KB + 1) * sizeof(cplx);
     if (smem > 64 * 1024) return QMG_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((2 * g.chr + SX - 1) / SX), g.cLy > 65535 ? 65535 : g.cLy);
-    if (KB == 8) k_bprolong_tile<T, 8><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
-    else if (KB == 4) k_bprolong_tile<T, 4><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
-    else k_bprolong_tile<T, 2><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, bi, s0, (long)cstride, (long)fstride, SX);
+    if (KB == 8) k_bprolong_tile<T, 8><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
+    else if (KB == 4) k_bprolong_tile<T, 4><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
+    else k_bprolong_tile<T, 2><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
     QMG_LAUNCH_CHECK();
   }
   return QMG_SUCCESS;
@@ -430,11 +548,22 @@ static int restrict_batch_impl(const void* nullvecs, int nvec, const void* fine,
   const long ncs = 2 * g.chalf_vol;
   const long nblk = (ncs + BLOCK / 32 - 1) / (BLOCK / 32);
   const unsigned gx = (unsigned)(nblk > 262144 ? 262144 : nblk);
+  const int nel = g.bx * g.by * g.fnc;
   for (int s0 = 0; s0 < bi.n; s0 += 8) {
     const int left = bi.n - s0;
-    if (left > 4) k_brestrict_tile<T, 8><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
-    else if (left > 2) k_brestrict_tile<T, 4><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
-    else k_brestrict_tile<T, 2><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, bi, s0, (long)cstride, (long)fstride);
+    const int KB = left > 4 ? 8 : left > 2 ? 4 : 2;
+    if (nel <= 32 && nvec <= 24 && g_xfer_tile != 2) {   // one element per lane, every load of a site in flight at once
+#define QMG_RS(KBV, NVTV) k_brestrict_small<T, KBV, NVTV><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, make_pass(bi, s0), (long)cstride, (long)fstride)
+#define QMG_RS_KB(KBV) { if (nvec <= 8) QMG_RS(KBV, 8); else if (nvec <= 16) QMG_RS(KBV, 16); else QMG_RS(KBV, 24); }
+      if (KB == 8) QMG_RS_KB(8) else if (KB == 4) QMG_RS_KB(4) else QMG_RS_KB(2)
+#undef QMG_RS_KB
+#undef QMG_RS
+      QMG_LAUNCH_CHECK();
+      continue;
+    }
+    if (left > 4) k_brestrict_tile<T, 8><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, make_pass(bi, s0), (long)cstride, (long)fstride);
+    else if (left > 2) k_brestrict_tile<T, 4><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, make_pass(bi, s0), (long)cstride, (long)fstride);
+    else k_brestrict_tile<T, 2><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, make_pass(bi, s0), (long)cstride, (long)fstride);
     QMG_LAUNCH_CHECK();
   }
   return QMG_SUCCESS;
