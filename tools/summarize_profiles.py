@@ -7,7 +7,7 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction
 """
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-kernel_key = sys.argv[2] if len(sys.argv) > 2 else "k_stencil_pair<2, 2"
+kernel_key = sys.argv[2] if len(sys.argv) > 2 else "k_stencil_pair<double, 2, 2"
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
@@ -38,6 +38,8 @@ out = {"tag": tag, "kernel": krow["Name"], "workload": "Wilson apply %dx%d nc=2 
        "hbm_read_bytes_per_launch_corrected": read_bytes, "hbm_write_bytes_per_launch": write_bytes,
        "hbm_traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg,
        "pmc_launches": [fn, wn], "pmc_avg_launch_us": [fdur, wdur],
+       "kernel_source_sha256": __import__("hashlib").sha256(open(os.path.join(ROOT, "quantum-mg_amd", "csrc", "qmg_stencil.hip"), "rb").read()).hexdigest(),
+       "git_head": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown",
        "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request on 16 B/lane streams), WRITE_SIZE exact; separate --pmc passes"}
 json.dump(out, open(os.path.join(P, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
