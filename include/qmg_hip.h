@@ -140,6 +140,19 @@ int qmg_wilson_fill(void* clover, void* hopping, const void* gauge, int Lx, int 
 int qmg_staggered_fill(void* hopping, const void* gauge, int Lx, int Ly, void* stream);                                /* staggered.h:50-72 */
 int qmg_laplace_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, void* stream);                    /* gaugedlaplace.h:45-68 */
 
+/* ---------------- U(1) gauge generation and observables (u1/u1_utils.h) ---------------- */
+/* Phase field: DEVICE double[2 Lx Ly], phase[mu*V + site] (gauge_coord_to_index); compact links U = exp(i A) in the same order.
+ * heatbath_noncompact_update (u1_utils.h:607-757) as a four-colour PARALLEL heatbath (x-links of even / odd rows, y-links of
+ * even / odd columns are conditionally independent): same Gibbs measure as the reference's sequential sweep, different
+ * update order and random stream.  `seed` and the running sweep number `first_sweep` key a counter-based generator. */
+int qmg_u1_heatbath_noncompact(double* phase, int Lx, int Ly, double beta, int n_update, unsigned long long seed,
+                               unsigned long long first_sweep, void* stream);
+int qmg_u1_phase_to_gauge(void* gauge, const double* phase, size_t n, void* stream);   /* polar_vector: U = exp(i A) */
+int qmg_u1_gauge_to_phase(double* phase, const void* gauge, size_t n, void* stream);   /* A = arg U (what write_gauge_u1 stores) */
+/* out_host[0..1] = average plaquette (get_plaquette_u1, :424-462), out_host[2] = topological charge (get_topo_u1, :465-508) */
+int qmg_u1_plaquette(const void* gauge, int Lx, int Ly, double* out_host, void* stream);
+int qmg_u1_noncompact_action(const double* phase, int Lx, int Ly, double beta, double* out_host, void* stream);   /* :386-421 */
+
 /* ---------------- stencil variants (device side) ---------------- */
 /* build_dagger_stencil (stencil_2d.h:1080-1139); also serves build_rbj_dagger_stencil (:1989-2060). */
 int qmg_build_dagger(void* dagger_clover, void* dagger_hopping, const void* clover, const void* hopping,

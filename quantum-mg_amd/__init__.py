@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
+    "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
 
@@ -464,6 +465,31 @@ def comm_all_ok(ok):
     out = C.c_int(0)
     check(lib().qmg_comm_all_ok(1 if ok else 0, C.byref(out)), "qmg_comm_all_ok")
     return bool(out.value)
+
+
+def u1_heatbath_noncompact(phase, Lx, Ly, beta, n_update, seed, first_sweep=0):
+    check(lib().qmg_u1_heatbath_noncompact(_vp(phase), Lx, Ly, C.c_double(beta), n_update, C.c_ulonglong(seed), C.c_ulonglong(first_sweep), None), "qmg_u1_heatbath_noncompact")
+
+
+def u1_phase_to_gauge(gauge, phase, n):
+    check(lib().qmg_u1_phase_to_gauge(_vp(gauge), _vp(phase), C.c_size_t(n), None), "qmg_u1_phase_to_gauge")
+
+
+def u1_gauge_to_phase(phase, gauge, n):
+    check(lib().qmg_u1_gauge_to_phase(_vp(phase), _vp(gauge), C.c_size_t(n), None), "qmg_u1_gauge_to_phase")
+
+
+def u1_plaquette(gauge, Lx, Ly):
+    """(average plaquette, topological charge)"""
+    out = (C.c_double * 3)()
+    check(lib().qmg_u1_plaquette(_vp(gauge), Lx, Ly, out, None), "qmg_u1_plaquette")
+    return complex(out[0], out[1]), out[2]
+
+
+def u1_noncompact_action(phase, Lx, Ly, beta):
+    out = C.c_double()
+    check(lib().qmg_u1_noncompact_action(_vp(phase), Lx, Ly, C.c_double(beta), C.byref(out), None), "qmg_u1_noncompact_action")
+    return out.value
 
 
 def set_tuning(key, value):

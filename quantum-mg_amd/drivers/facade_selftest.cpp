@@ -13,6 +13,8 @@
 #include <iostream>
 #include <string>
 
+#include <unistd.h>
+
 #include "../include/qmg/qmg.hpp"
 
 using namespace std;
@@ -181,6 +183,50 @@ int main(int argc, char** argv) {
     built.pop_level();
     check(built.get_num_levels() == 1, "MultigridMG pop_level", built.get_num_levels());
     for (complex<double>** p : {&vc, &vf, &vc2, &o1, &o2}) deallocate_vector(p);
+    for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
+    delete[] nv;
+  }
+
+  // ---- n01 / n14: U(1) utilities (u1/u1_utils.h): write_gauge_u1 -> read_gauge_u1 round trip in the reference's text format,
+  //      plaquette / topology of the stored configuration, a non-compact heatbath step, coarse-shift bookkeeping
+  {
+    const string tmp_cfg = string(getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp") + "/qmg_selftest_cfg." + to_string((long)getpid()) + ".dat";
+    write_gauge_u1(gauge, &lat1, tmp_cfg);
+    complex<double>* g2 = allocate_vector<complex<double>>(lat1.get_size_gauge());
+    const bool rd = read_gauge_u1(g2, &lat1, tmp_cfg);
+    std::remove(tmp_cfg.c_str());
+    check(rd && sqrt(diffnorm2sq(gauge, g2, lat1.get_size_gauge()) / norm2sq(gauge, lat1.get_size_gauge())) < 1e-15, "write_gauge_u1 -> read_gauge_u1 round trip",
+          sqrt(diffnorm2sq(gauge, g2, lat1.get_size_gauge())));
+    const complex<double> plaq = get_plaquette_u1(gauge, &lat1);
+    const double topo = get_topo_u1(gauge, &lat1);
+    check(plaq.real() > 0.85 && plaq.real() < 0.97 && fabs(topo - std::round(topo)) < 1e-9, "plaquette of the beta = 6.0 fixture in (0.85, 0.97), integer topological charge", plaq.real());
+    double* ph = allocate_vector<double>(lat1.get_size_gauge());
+    qmg::ok(qmg_u1_gauge_to_phase(ph, gauge, (size_t)lat1.get_size_gauge(), 0), "qmg_u1_gauge_to_phase");
+    const double s0 = get_noncompact_action_u1(ph, 6.0, &lat1);
+    HeatbathRng rng(99ull);
+    heatbath_noncompact_update(ph, &lat1, 6.0, 50, rng);
+    polar_vector(ph, g2, (size_t)lat1.get_size_gauge());
+    const double p1 = get_plaquette_u1(g2, &lat1).real(), s1 = get_noncompact_action_u1(ph, 6.0, &lat1) / (L * L);
+    check(rng.sweeps_done == 50 && p1 > 0.88 && p1 < 0.96 && s1 > 0.4 && s1 < 0.6 && s0 > 0.0, "heatbath at beta = 6.0 keeps the plaquette near exp(-1/12), action per plaquette near 1/2", p1);
+    deallocate_vector(&ph); deallocate_vector(&g2);
+  }
+  // ---- coarse shift after a variant swap (deliberate deviation from coarse.h:131, which leaves shift_backup at 0)
+  {
+    const int nvec = 4;
+    Lattice2D latc(L / 4, L / 4, nvec);
+    Wilson2D wm(&lat2, complex<double>(0.13, 0.0), gauge);
+    complex<double>** nv = new complex<double>*[nvec];
+    for (int j = 0; j < nvec; j++) { nv[j] = allocate_vector<complex<double>>(n2); gaussian(nv[j], n2, 500ull + j); }
+    TransferMG tr(&lat2, &latc, nv, true, false, QMG_DOUBLE_NONE);
+    CoarseOperator2D co(&latc, &wm, &lat2, &tr, false, false, CoarseOperator2D::QMG_COARSE_BUILD_DAGGER);
+    const long ncv = latc.get_size_cv_l();
+    complex<double>*v = allocate_vector<complex<double>>(ncv), *a1 = allocate_vector<complex<double>>(ncv), *a2 = allocate_vector<complex<double>>(ncv);
+    gaussian(v, ncv, 600ull);
+    zero_vector(a1, ncv); co.apply_M(a1, v);
+    zero_vector(a2, ncv); co.apply_M_dagger(a2, v);   // swaps the dagger stencil in and out again
+    zero_vector(a2, ncv); co.apply_M(a2, v);
+    check(co.get_shift() == complex<double>(0.13, 0.0) && diffnorm2sq(a1, a2, ncv) == 0.0, "coarse operator keeps its (non-zero) shift across a dagger swap", co.get_shift().real());
+    for (complex<double>** p : {&v, &a1, &a2}) deallocate_vector(p);
     for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
     delete[] nv;
   }

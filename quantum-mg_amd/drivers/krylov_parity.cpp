@@ -1,7 +1,7 @@
 // krylov_parity -- runs each Krylov driver of include/qmg/krylov.hpp (the device restatement of the absent quantum-linalg
 // inverters) on ONE fixed system and dumps right-hand sides and solutions, so that
-// tests/test_gpu_krylov.py can hold every driver to its CPU twin in the test infrastructure (
-// pinned there to scipy): same iteration counts (+-1), same solutions.
+// tests/test_gpu_krylov.py can hold every driver to its CPU twin in the test infrastructure (the twins are pinned to scipy
+// in tests/test_oracle_krylov.py): same iteration counts (+-1), same solutions.
 //   ./krylov_parity L mass gauge_file dump_dir
 // Systems: Wilson (nc = 2) at `mass` on the L x L gauge file for BiCGStab-L (L = 1, 6: n13:359 uses 6), Richardson (n22:289
 // parameters), MR(0.85) (the K-cycle smoother), restarted GCR(8) and unrestarted GCR, CG on M^dagger M (the coarsest

@@ -60,7 +60,11 @@ struct CoarseOperator2D : public Stencil2D {
       default: default_chirality = QMG_CHIRALITY_NONE; break;
     }
     if (use_rbjacobi) fine_stencil->perform_swap_rbjacobi();   // :120-123 (zeroes the fine shifts while swapped)
-    shift = shift_backup = fine_stencil->get_shift();           // :131  only the identity shift is transferred
+    // :131 transfers only the identity shift -- and sets only `shift`, leaving shift_backup at its constructor value 0, so that
+    // in the reference any later swap-back (dagger / rbjacobi applies: perform_swap_* restores the backups) silently resets a
+    // Galerkin operator's shift to 0.  DELIBERATE DEVIATION: the backup is set too, so CGNE smoothers / MDM / RBJACOBI builds on
+    // an ORIGINAL-built coarse operator keep the mass term (facade_selftest checks apply_M before and after a dagger swap).
+    shift = shift_backup = fine_stencil->get_shift();
     qmg_stencil_desc fd = fine_stencil->desc();
     qmg::ok(qmg_coarse_build(clover, hopping, &fd, transfer->device_null_vectors(), transfer->device_restrict_vectors(), lat->get_dim_mu(0),
                              lat->get_dim_mu(1), lat->get_nc(), qmg::current_stream()), "qmg_coarse_build");
