@@ -209,6 +209,10 @@ int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
 /* block_orthonormalize, one pass, in place (:514-607); cholesky (cLx*cLy*nvec*nvec complex) may be NULL. */
 int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
                              void* cholesky, void* stream);
+/* `passes` (1 or 2) passes in ONE launch -- the TransferMG constructor runs two (:160-174), the factor saved in the first:
+ * each block's nvec x (bx by nc_f) tile is read once, orthonormalised in LDS, written once.  Asynchronous, no allocation. */
+int qmg_block_orthonormalize_n(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
+                               void* cholesky, int passes, void* stream);
 
 /* block_bi_orthonormalize, one pass, in place (:610-769): separate prolongator / restrictor vectors made block
  * bi-orthonormal (R^dag P = 1 per block); block_L / block_U (cLx*cLy*nvec*nvec complex each) may be NULL. */
@@ -299,6 +303,8 @@ int qmg_comm_finalize(void);
  *   "gen32"         fp32-stored matrices, even nc: 1 = fp32 tile end to end (kernel B32), 2 = same with 2-site tiles,
  *                   0 = kernel B with widening loads (1)
  *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
+ *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);
+ *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)
  * (The ablation switch of tools/variants.py exists only in the tools build, `make DIAG=1`; this library has no such key.) */
 int qmg_set_tuning(const char* key, int value);
 

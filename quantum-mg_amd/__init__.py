@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
     "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
-    "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
+    "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_orthonormalize_n", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",

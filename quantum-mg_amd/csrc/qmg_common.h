@@ -167,6 +167,7 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
   return b;
 }
 
+extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
 extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
 
 // Memory-bound 1-D launches.  One 16-byte element per thread up to 2^18 blocks, grid-stride beyond: on this part a

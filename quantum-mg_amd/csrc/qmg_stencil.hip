@@ -1009,6 +1009,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_tile")) { g_xfer_tile = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "setup_fused")) { g_setup_fused = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 

@@ -630,8 +630,11 @@ int qmg_restrict_batch(const void* nullvecs, int nvec, const void* fine, void* c
 // block_orthonormalize (transfer.h:514-607): the reference's own formulation -- classical
 // Gram-Schmidt per block phrased as single-vector restrict / prolong -- driven from the host,
 // every pass a device kernel.  O(nvec^2) launches; setup-time only.
-int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
-                             void* cholesky, void* stream) {
+}  // extern "C"
+namespace qmg {
+// (fallback of qmg_block_orthonormalize_n, csrc/qmg_setup.hip: odd block widths, tiles beyond LDS, "setup_fused" 0)
+int block_orthonormalize_passes(void* nullvecs, int nvec, int fLx, int fLy, int fnc, int cLx, int cLy,
+                                void* cholesky, void* stream) {
   if (!nullvecs || nvec < 1) return QMG_ERR_INVALID;
   XferGeom g;
   const int cnc = nvec;
@@ -670,6 +673,9 @@ int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc
   if (!rc) QMG_LAUNCH_CHECK();
   return rc;
 }
+
+}  // namespace qmg
+extern "C" {
 
 // block_bi_orthonormalize, one pass, in place (transfer.h:610-769): the asymmetric (P != R^dag) counterpart.
 // pvecs = prolongator vectors, rvecs = restrictor vectors; afterwards R^dag P = 1 block by block.
@@ -730,8 +736,11 @@ int qmg_block_bi_orthonormalize(void* pvecs, void* rvecs, int nvec, int fLx, int
 
 // CoarseOperator2D ctor, steps 1-2 (coarse.h:137-444): 9 probes per coarse colour, each
 // unit vector -> prolong -> partial fine apply -> restrict -> scatter into column `color`.
-int qmg_coarse_build(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs,
-                     const void* restrict_vecs, int cLx, int cLy, int cnc, void* stream) {
+}  // extern "C"
+namespace qmg {
+// (fallback of qmg_coarse_build, csrc/qmg_setup.hip: more than 32 coarse colours, fine blocks beyond LDS, "setup_fused" 0)
+int coarse_build_probes(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs,
+                        const void* restrict_vecs, int cLx, int cLy, int cnc, void* stream) {
   if (!cclover || !chopping || !fine || !nullvecs) return QMG_ERR_INVALID;
   XferGeom g;
   int rc = make_geom(&g, fine->Lx, fine->Ly, fine->nc, cLx, cLy, cnc);
@@ -779,4 +788,4 @@ int qmg_coarse_build(void* cclover, void* chopping, const qmg_stencil_desc* fine
   return rc;
 }
 
-}  // extern "C"
+}  // namespace qmg

@@ -108,12 +108,16 @@ inline int N13::build(int argc, char** argv) {
 
   int curr_x_len = x_len, curr_y_len = y_len;
   transfer_objs = new TransferMG*[n_refine];
+  double t_null = 0.0, t_ortho = 0.0, t_galerkin = 0.0;   // setup split: null-vector relaxation / block orthonormalisation / Galerkin build
+  auto now = [] { qmg_stream_sync(0); return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   for (int i = 1; i <= n_refine; i++) {
     curr_x_len /= x_block; curr_y_len /= y_block;
     lats[i] = new Lattice2D(curr_x_len, curr_y_len, coarse_dof);
     const long fsize = lats[i - 1]->get_size_cv_l();
     complex<double>** null_vectors = new complex<double>*[coarse_dof];
     for (int j = 0; j < coarse_dof; j++) { null_vectors[j] = allocate_vector<complex<double>>(fsize); zero_vector(null_vectors[j], fsize); }
+    auto t0 = now();
     for (int j = 0; j < coarse_dof / 2; j++) {
       complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
       gaussian(rand_guess, fsize, seed++);
@@ -142,7 +146,9 @@ inline int N13::build(int argc, char** argv) {
       }
       fclose(f);
     }
+    auto t1 = now();
     transfer_objs[i - 1] = new TransferMG(lats[i - 1], lats[i], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
+    auto t2 = now();
     level_solve_objs[i - 1] = new StatefulMultigridMG::LevelSolveMG;
     level_solve_objs[i - 1]->fine_stencil_app = QMG_MATVEC_ORIGINAL;
     level_solve_objs[i - 1]->intermediate_tol = inner_tol;
@@ -153,12 +159,16 @@ inline int N13::build(int argc, char** argv) {
     level_solve_objs[i - 1]->post_tol = post_smooth_tol;
     level_solve_objs[i - 1]->post_iters = n_post_smooth;
     mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, true, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL, null_vectors);
+    auto t3 = now();
+    t_null += secs(t0, t1); t_ortho += secs(t1, t2); t_galerkin += secs(t2, t3);
     for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
     delete[] null_vectors;
     cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
   }
   qmg_stream_sync(0);
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
+  cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
+       << " s ; total " << setup_s << " s\n" << setprecision(20);
 
   return 0;
 }

@@ -49,10 +49,11 @@ class TransferMG {
     for (int i = 0; i < const_num_null_vec; i++) copy_vector(store + i * fsize, vecs[i], fsize);
     return store;
   }
-  void one_ortho_pass(complex<double>* chol) {
-    qmg::ok(qmg_block_orthonormalize(null_store, const_num_null_vec, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
-                                     coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), chol, qmg::current_stream()),
-            "qmg_block_orthonormalize");
+  // `passes` Gram-Schmidt passes per block in one launch (tile in LDS; csrc/qmg_setup.hip), the factor saved in the first
+  void ortho_passes(complex<double>* chol, int passes) {
+    qmg::ok(qmg_block_orthonormalize_n(null_store, const_num_null_vec, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
+                                       coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), chol, passes, qmg::current_stream()),
+            "qmg_block_orthonormalize_n");
   }
 
  public:
@@ -76,8 +77,7 @@ class TransferMG {
       zero_vector(block_cholesky, coarse_lat->get_size_cm_l());
     }
     if (do_block_ortho) {   // twice; the decomposition is saved on the first pass only (:160-174)
-      one_ortho_pass(block_cholesky);
-      one_ortho_pass(0);
+      ortho_passes(block_cholesky, 2);
     }
     is_init = true;
   }

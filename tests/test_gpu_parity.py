@@ -478,6 +478,46 @@ def test_block_orthonormalize_and_n05_identities(fdims, cdims):
     assert cs.rel_l2(dc.to_host(), vc) < 1e-13
 
 
+@pytest.mark.parametrize("fdims,cdims", [((32, 32, 2), (8, 8, 24)), ((16, 16, 24), (4, 4, 24)), ((16, 8, 8), (4, 2, 8)), ((8, 8, 2), (4, 4, 6)), ((12, 12, 2), (4, 4, 4))])
+def test_block_local_setup_kernels_match_the_oracle_and_the_full_lattice_passes(fdims, cdims):
+    """csrc/qmg_setup.hip: block orthonormalisation with the tile in LDS, BOTH passes of the TransferMG
+    constructor in one launch (32-, 128- and 256-thread groups: nel = 32, 128, 384), and the Galerkin build as per-block
+    products, with a separate restrictor -- against the oracle (1e-12) and against the first round's full-lattice passes
+    ("setup_fused" 0; also the fallback for the odd block width of the last case)."""
+    fLx, fLy, fnc = fdims
+    fvol, fsize = fLx * fLy, fLx * fLy * fnc
+    nvec = cdims[2]
+    nv = cs.gaussian_cvec(nvec * fsize, 21)
+    ccm = cdims[0] * cdims[1] * nvec * nvec
+    chol = np.zeros(ccm, dtype=np.complex128)
+    want = ol.block_orthonormalize(nv.copy(), fdims, cdims, cholesky=chol)
+    want = ol.block_orthonormalize(want, fdims, cdims)                       # second pass, no factor
+    got = {}
+    for fused in (1, 0):
+        qmg.set_tuning("setup_fused", fused)
+        dnv, dchol = D(nv), qmg.DeviceArray.zeros(ccm)
+        qmg.check(qmg.lib().qmg_block_orthonormalize_n(qmg._vp(dnv), nvec, fLx, fLy, fnc, cdims[0], cdims[1], qmg._vp(dchol), 2, None))
+        got[fused] = (dnv.to_host(), dchol.to_host())
+        assert cs.rel_l2(got[fused][0], want) < 1e-12 and cs.rel_l2(got[fused][1], chol) < 1e-12, fused
+    assert cs.rel_l2(got[1][0], got[0][0]) < 1e-12
+    # Galerkin build, restrictor != prolongator
+    clover, hopping = cs.gaussian_cvec(fvol * fnc * fnc, 1), cs.gaussian_cvec(4 * fvol * fnc * fnc, 2)
+    pv = want
+    rv = want + 0.2 * cs.gaussian_cvec(nvec * fsize, 22)
+    od = ol.make_desc(fLx, fLy, fnc, clover, hopping, 0.1)
+    for rvecs in (None, rv):
+        cclover, chopping = ol.coarse_build(od, pv, cdims, restrict_vecs=rvecs)
+        dcl, dho, dpv = D(clover), D(hopping), D(pv)
+        drv = None if rvecs is None else D(rvecs)
+        gd = qmg.make_desc(fLx, fLy, fnc, dcl, dho, 0.1)
+        for fused in (1, 0):
+            qmg.set_tuning("setup_fused", fused)
+            gcc, gch = qmg.DeviceArray(cclover.size), qmg.DeviceArray(chopping.size)
+            qmg.coarse_build(gcc, gch, gd, dpv, cdims, restrict_vecs=drv)
+            assert cs.rel_l2(gcc.to_host(), cclover) < 1e-12 and cs.rel_l2(gch.to_host(), chopping) < 1e-12, (fused, rvecs is None)
+    qmg.set_tuning("setup_fused", 1)
+
+
 @pytest.mark.parametrize("fdims,cdims", XFER_CASES[:4])
 def test_block_bi_orthonormalize_asymmetric_transfer(fdims, cdims):
     """transfer.h:610-769 (P != R^dag, tests/n05_prolong_restrict_test:105-139): after bi-orthonormalisation R^dag P = 1
