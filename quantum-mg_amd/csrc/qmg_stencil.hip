@@ -789,8 +789,8 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // at 512^2, nc = 24, 16 rhs: the extra f64 adds and the third accumulator cost more than the saved MFMA -- and dropped.)
 // The f64 matrix pipe sustains 48 TFLOP/s on this part (tools/mfma_f64_rate.hip), which at nc = 24 is 2.7 ms of plain
 // MFMA work per 512^2 apply against 2.4 ms of HBM time -- the MFMA count, not the byte count, is what MODE 1 cuts.
-template <int NC, int MODE, bool M32, bool V32>
-__global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, const int nk) {
+template <int NC, int MODE, bool M32, bool V32, bool VL>
+__global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
   constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
   constexpr int NACC = 2;
   // LDS row stride in tile elements: fp64 tile nc+1 complex (odd: conflict-free 16-B reads); fp32-stored matrices keep the
@@ -836,10 +836,27 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
       for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     constexpr int NGP = (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS per lane per piece (fp32-stored matrices)
-    cplx G[M32 ? NGP : NG];   // M32: raw bits of two complex<float> per entry
+    // staging registers for the matrix stream (a second set, two pieces of prefetch, was measured SLOWER: 8 rhs 2.88 -> 3.10
+    // ms; the registers cost a resident wavefront and the stream was not the limit -- profiles/r02_mfma_kernelC_variants.txt)
+    constexpr int NGS = M32 ? NGP : NG;
+    cplx G[1][NGS];   // M32: raw bits of two complex<float> per entry
+    // Right-hand sides.  VL = false (round 1): each lane loads its B-operand entries X_k[4q + lq] straight from global memory --
+    // 16 right-hand sides x 64-byte pieces per instruction, 16 cache lines touched per load, 6 loads per piece; going from 4
+    // to 8 right-hand sides cost 0.48 ms of a 2.9 ms apply.  VL = true: the piece's nk x NC block is loaded COALESCED
+    // (lane-linear over [k][c]: whole 384-byte site vectors), parked in a second LDS slice of the wavefront with rows padded
+    // to NC+1 (conflict-free 16-byte fragment reads), and the B fragments are read from there just in time.  The epilogue
+    // goes back the same way: results into the slice, then coalesced read-modify-write of the output vectors.
+    constexpr int XS = NC + 1;                                   // padded row of the vector slice
+    constexpr int XROWS = (MODE == 1) ? 8 : 16;                  // right-hand sides a pass can hold (MODE 1: at most 8)
+    constexpr int NXG = (XROWS * NC + WAVE - 1) / WAVE;          // staged vector elements per lane per piece
+    cplx XG[VL ? NXG : 1];
+    cplx* xlds = reinterpret_cast<cplx*>(smem_raw + (M32 ? sizeof(float2) : sizeof(cplx)) * (size_t)(BLOCK / WAVE) * NC * RS) + (size_t)wave * XROWS * XS;
     // MODE 1 needs only the half of X its column carries (re for columns 0-7, im for 8-15): one double per k-step
-    typename std::conditional<MODE == 1, double, cplx>::type B[2][KS];
-    auto load_piece = [&](int pc, int set) {      // global -> registers: matrix (lane-linear) and the k right-hand sides
+    typename std::conditional<MODE == 1, double, cplx>::type B[2][VL ? 1 : KS];
+    auto nb_of = [&](int pc) -> long {            // neighbour site of piece slot pc
+      return pc == 0 ? site : pc == 1 ? nb[1] : pc == 2 ? nb[2] : pc == 3 ? nb[3] : nb[4];
+    };
+    auto load_matrix = [&](int pc, int gs) {      // global -> registers, lane-linear, non-temporal
       const cplx* mbase = (pc == 0) ? a.clover : a.hopping;
       const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * NC2;
       if (M32) {   // pairs of complex<float>: 16 B per lane per load, kept as raw bits
@@ -848,39 +865,59 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           const int el = 2 * (g * WAVE + lane);
           if (NC2 % (2 * WAVE) == 0 || el < NC2) {
             const double* pp = reinterpret_cast<const double*>(reinterpret_cast<const float2*>(mbase) + moff + el);
-            G[g].x = __builtin_nontemporal_load(pp);
-            G[g].y = __builtin_nontemporal_load(pp + 1);
-          } else G[g] = cmake(0.0, 0.0);
+            G[gs][g].x = __builtin_nontemporal_load(pp);
+            G[gs][g].y = __builtin_nontemporal_load(pp + 1);
+          } else G[gs][g] = cmake(0.0, 0.0);
         }
       } else {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
           const int el = g * WAVE + lane;
-          G[g] = (NC2 % WAVE == 0 || el < NC2) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
+          G[gs][g] = (NC2 % WAVE == 0 || el < NC2) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
         }
       }
-      const long xo = koff + nb[pc] * NC;
+    };
+    auto load_vectors = [&](int pc, int set) {    // the k right-hand sides at the piece's neighbour site
+      if constexpr (VL) {                         // lane-linear over [k][c]: element e = g*64 + lane -> (k = e / NC, c = e % NC)
+        const long so = nb_of(pc) * NC;
 #pragma unroll
-      for (int q = 0; q < KS; q++) {
-        const int c = 4 * q + lq;
-        const cplx xv = (kval && c < NC) ? ldv<V32>(a.rhs, xo + c) : cmake(0.0, 0.0);
-        if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
-        else B[set][q] = xv;
+        for (int g = 0; g < NXG; g++) {
+          const int e = g * WAVE + lane;
+          const int k = e / NC, c = e - k * NC;
+          XG[g] = (k < nk) ? ldv<V32>(a.rhs, rhs_offset(a, k) + so + c) : cmake(0.0, 0.0);
+        }
+      } else {
+        const long xo = koff + nb_of(pc) * NC;    // B-operand layout straight from global memory
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+          const int c = 4 * q + lq;
+          const cplx xv = (kval && c < NC) ? ldv<V32>(a.rhs, xo + c) : cmake(0.0, 0.0);
+          if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
+          else B[set][q] = xv;
+        }
       }
     };
-    auto park_piece = [&]() {                     // registers -> this wavefront's LDS slice, padded rows
+    auto park_piece = [&](int gs) {               // registers -> this wavefront's LDS slice, padded rows
       wave_lds_handoff();                         // the previous piece's fragment reads are done
       if (M32) {
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
           const int el = 2 * (g * WAVE + lane);
-          if (NC2 % (2 * WAVE) == 0 || el < NC2) *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[g];   // 16-B aligned: RS, el even
+          if (NC2 % (2 * WAVE) == 0 || el < NC2) *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[gs][g];   // 16-B aligned: RS, el even
         }
       } else {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
           const int el = g * WAVE + lane;
-          if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[g];
+          if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[gs][g];
+        }
+      }
+      if constexpr (VL) {                         // the right-hand sides of the same piece, rows padded
+#pragma unroll
+        for (int g = 0; g < NXG; g++) {
+          const int e = g * WAVE + lane;
+          const int k = e / NC, c = e - k * NC;
+          if (k < XROWS) xlds[k * XS + c] = XG[g];
         }
       }
       wave_lds_handoff();
@@ -898,22 +935,29 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           } else
             Af[t] = ((NC % 16 == 0 || r < NC) && (NC % 4 == 0 || c < NC)) ? mlds[r * RS + c] : cmake(0.0, 0.0);
         }
+        if constexpr (VL) {                       // B fragment of this k-step: X_{column}[4q + lq] from the wavefront's vector slice
+          const int c = 4 * q + lq;
+          const cplx xv = (NC % 4 == 0 || c < NC) ? xlds[kcol * XS + c] : cmake(0.0, 0.0);
+          if constexpr (MODE == 1) B[set][0] = (lr < 8) ? xv.x : xv.y;
+          else B[set][0] = xv;
+        }
+        constexpr int qb = VL ? 0 : 1;            // VL: the fragment sits in slot 0; else slot q
         if constexpr (MODE == 0) {
 #pragma unroll
           for (int t = 0; t < RT; t++) {
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q].x, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q].y, acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q * qb].x, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q * qb].y, acc[1][t], 0, 0, 0);
           }
 #pragma unroll
           for (int t = 0; t < RT; t++) {
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Af[t].y, B[set][q].y, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q].x, acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Af[t].y, B[set][q * qb].y, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q * qb].x, acc[1][t], 0, 0, 0);
           }
         } else {
 #pragma unroll
           for (int t = 0; t < RT; t++) {
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q], acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q * qb], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].y, B[set][q * qb], acc[1][t], 0, 0, 0);
           }
         }
       }
@@ -921,32 +965,46 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
 
     // software pipeline over the five piece slots (activity is uniform over the block).  Slot pc+1 is prefetched while
     // slot pc computes; a slot whose predecessor is inactive loads on demand.  All register-set indices are
-    // compile-time constants after unrolling.
-    if (act[0]) load_piece(0, 0);
+    // compile-time constants after unrolling.  (VL: the right-hand sides of slot pc are parked with its matrices, so their
+    // registers are free again before slot pc+1 is fetched.)
+    if (act[0]) { load_matrix(0, 0); load_vectors(0, 0); }
 #pragma unroll
     for (int pc = 0; pc < 5; pc++) {
       if (!act[pc]) continue;
-      if (pc > 0 && !act[pc - 1]) load_piece(pc, pc & 1);
-      park_piece();                               // G held piece pc; it is free again after this
-      if (pc + 1 < 5 && act[pc + 1]) load_piece(pc + 1, (pc + 1) & 1);
+      if (pc > 0 && !act[pc - 1]) { load_matrix(pc, 0); load_vectors(pc, pc & 1); }
+      park_piece(0);                              // G (and XG) held piece pc; they are free again after this
+      if (pc + 1 < 5 && act[pc + 1]) { load_matrix(pc + 1, 0); load_vectors(pc + 1, (pc + 1) & 1); }
       mac_piece(pc & 1);
     }
 
     // epilogue: shift, accumulate, store.  Lane (lq, lr) owns rows 16 t + 4 i + lq of right-hand side lr.
     const double sg = p ? -1.0 : 1.0;
+    if constexpr (VL) {
+      // results into the vector slice [k][r] (the last piece's fragment reads are done), then lane-linear over [k][r]:
+      // coalesced own-site read for the shift term, coalesced read-modify-write of the output
+      wave_lds_handoff();
 #pragma unroll
-    for (int t = 0; t < RT; t++) {
+      for (int t = 0; t < RT; t++) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int r = 16 * t + 4 * i + lq;
-        cplx v;
-        if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
-        else {   // partner lane (lr ^ 8) holds the other half of the packed columns
-          const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
-          v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+        for (int i = 0; i < 4; i++) {
+          const int r = 16 * t + 4 * i + lq;
+          cplx v;
+          if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
+          else {   // partner lane (lr ^ 8) holds the other half of the packed columns
+            const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
+            v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+          }
+          if (r < NC && (MODE != 1 || lr < 8)) xlds[kcol * XS + r] = v;
         }
-        if (r < NC && kval && (MODE != 1 || lr < 8)) {
-          const long o = koff + site * NC + r;
+      }
+      wave_lds_handoff();
+#pragma unroll
+      for (int g = 0; g < NXG; g++) {
+        const int e = g * WAVE + lane;
+        const int k = e / NC, r = e - k * NC;
+        if (k < nk) {
+          cplx v = xlds[k * XS + r];
+          const long o = rhs_offset(a, k) + site * NC + r;
           if (do_shift) {
             const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
             const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
@@ -954,6 +1012,31 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_mfma(const StencilArgs a, con
           }
           if (!do_zero) v = cadd(ldv<V32>(a.lhs, o), v);
           stv<V32>(a.lhs, o, v);
+        }
+      }
+      wave_lds_handoff();   // the next row's first park must not overtake these reads
+    } else {
+#pragma unroll
+      for (int t = 0; t < RT; t++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int r = 16 * t + 4 * i + lq;
+          cplx v;
+          if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
+          else {   // partner lane (lr ^ 8) holds the other half of the packed columns
+            const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
+            v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+          }
+          if (r < NC && kval && (MODE != 1 || lr < 8)) {
+            const long o = koff + site * NC + r;
+            if (do_shift) {
+              const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+              const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+              cmac(v, sh, ldv<V32>(a.rhs, o));
+            }
+            if (!do_zero) v = cadd(ldv<V32>(a.lhs, o), v);
+            stv<V32>(a.lhs, o, v);
+          }
         }
       }
     }
@@ -967,6 +1050,7 @@ static int g_stencil_ablate = 0;
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
+static int g_mfma_vl = 1;        // tuning knob: 1 = kernel C loads / stores the right-hand sides coalesced through an LDS slice, 0 = operand-layout global accesses
 static int g_gen32 = 1;          // tuning knob: fp32-stored matrices, even nc: 1 = kernel B32 (fp32 tile end to end), 2 = same with 2-site tiles, 0 = kernel B with widening loads
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
 
@@ -1008,6 +1092,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "mfma_vl")) { g_mfma_vl = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_tile")) { g_xfer_tile = value; return QMG_SUCCESS; }
   if (!strcmp(key, "setup_fused")) { g_setup_fused = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
@@ -1173,14 +1258,16 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       b.lhs = (char*)a.lhs + (size_t)k0 * a.vec_stride * (vec32 ? 8 : 16);
       b.rhs = (const char*)a.rhs + (size_t)k0 * a.vec_stride * (vec32 ? 8 : 16);
       const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
-      const size_t smem = a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * nc * (nc + 2) : sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
+      size_t smem = a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * nc * (nc + 2) : sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
       const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
-#define QMG_MFMA_LAUNCH1(NC, MODE, M32, V32)                                                                    \
+      if (g_mfma_vl && !(mode == 0 && a.mat32)) smem += sizeof(cplx) * (size_t)(BLOCK / WAVE) * (mode == 1 ? 8 : 16) * (nc + 1);   // the wavefronts' vector slices
+#define QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, VL)                                                              \
       {                                                                                                         \
         if (smem > 64 * 1024)                                                                                   \
-          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, M32, V32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        k_stencil_mfma<NC, MODE, M32, V32><<<grid, block, smem, st>>>(b, nk);                                   \
+          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, M32, V32, VL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        k_stencil_mfma<NC, MODE, M32, V32, VL><<<grid, block, smem, st>>>(b, nk);                             \
       }
+#define QMG_MFMA_LAUNCH1(NC, MODE, M32, V32) { if (g_mfma_vl && !(MODE == 0 && M32)) QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, true) else QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, false) }
 #define QMG_MFMA_LAUNCH2(NC, MODE)                                                                              \
       { if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
@@ -1194,6 +1281,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       }
 #undef QMG_MFMA_LAUNCH
 #undef QMG_MFMA_LAUNCH1
+#undef QMG_MFMA_LAUNCH0
 #undef QMG_MFMA_LAUNCH2
     }
     QMG_LAUNCH_CHECK();

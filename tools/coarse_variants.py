@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (before libqmg_hip)
 qmg = importlib.import_module("quantum-mg_amd")
 qmg.init(0)
+qmg.set_tuning("stencil_nt", 3)
 L = int(sys.argv[1]); nc = int(sys.argv[2])
 variants = json.loads(sys.argv[3])
 nrhs = int(sys.argv[4]) if len(sys.argv) > 4 else 1
