@@ -272,6 +272,13 @@ int qmg_prolong_batch_t(int dtype, const void* nullvecs, int nvec, const void* c
 int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
                          int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
 
+/* 16-bit storage of the fine operator (SURVEY 8f-4 "16-bit-storage smoother"; nc = 2 only): d->clover / d->hopping point to
+ * complex<half> copies (qmg_convert_to_c16), vectors are complex<float>, arithmetic fp32: 112 B/site instead of 192.  The
+ * rounding (2^-11) perturbs the OPERATOR, so this is for applies inside a preconditioner only. */
+int qmg_convert_to_c16(void* dst_c16, const void* src, int src_dtype, size_t n, void* stream);
+int qmg_stencil_apply_h16(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                          int nrhs, size_t vec_stride, unsigned mask, void* stream);
+
 /* ---------------- multi-GPU: independent right-hand sides per rank ---------------- */
 /* The path shards over right-hand sides; every rank holds a replica of the stencil/transfer data and
  * there is no halo exchange.  The one collective is a sum all-reduce (RCCL over xGMI) of a small

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
+    "qmg_convert_to_c16", "qmg_stencil_apply_h16",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -455,6 +456,15 @@ def prolong_batch_t(dtype, nullvecs, nvec, coarse, fine, fdims, cdims, nrhs, cst
 def restrict_batch_t(dtype, nullvecs, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
     check(lib().qmg_restrict_batch_t(dtype, _vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
           "qmg_restrict_batch_t")
+
+
+def convert_to_c16(dst, src, src_dtype, n):
+    check(lib().qmg_convert_to_c16(_vp(dst), _vp(src), src_dtype, C.c_size_t(n), None), "qmg_convert_to_c16")
+
+
+def stencil_apply_h16(desc, lhs, rhs, pieces, nrhs=1, vec_stride=0, mask=1, stream=None):
+    check(lib().qmg_stencil_apply_h16(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
+          "qmg_stencil_apply_h16")
 
 
 def comm_init_env(world, rank):

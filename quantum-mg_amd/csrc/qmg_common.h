@@ -40,6 +40,11 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline bool valid_lattice(int Lx, int Ly) { return Lx >= 2 && Ly >= 2 && !(Lx & 1) && !(Ly & 1); }
 
+// qmg_site.hip: nc = 2 apply; storage 0 = complex<half> matrices + complex<float> vectors, 1 = complex<float>, 2 = complex<double>
+int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride,
+                      const unsigned char* ridx, hipStream_t st, bool only_where_faster);
+constexpr int SITE_DECLINED = 1000;   // not an error: the caller's own kernel is the better one for this launch
+
 // ---------------- complex arithmetic (explicit FMAs; 8 flop per MAC) ----------------
 __device__ __forceinline__ cplx cmake(double re, double im) { return make_double2(re, im); }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -169,6 +174,7 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
 
 extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
 extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
+extern int g_site_block, g_site_gy;   // qmg_site.hip; "site_block", "site_gy"
 
 // Memory-bound 1-D launches.  One 16-byte element per thread up to 2^18 blocks, grid-stride beyond: on this part a
 // streaming copy reaches 6.2 TB/s at 262 144 blocks but only 5.4 TB/s at 8 192 (profiles/r01_membw_ceiling.txt).

@@ -1047,6 +1047,7 @@ static int g_stencil_nt = 3;     // tuning knob: bit0 non-temporal matrix loads,
 #ifdef QMG_DIAGNOSTICS
 static int g_stencil_ablate = 0;
 #endif
+static int g_stencil_site = 3;    // tuning knob: nc 2 through the site kernel (qmg_site.hip): bit 0 fp64 where it is faster, bit 1 fp32, bit 2 fp64 always
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
@@ -1088,6 +1089,9 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
 #endif
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "stencil_site")) { g_stencil_site = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "site_block")) { if (value != 64 && value != 128 && value != 256) return QMG_ERR_INVALID; g_site_block = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "site_gy")) { g_site_gy = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
@@ -1167,6 +1171,11 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.rhs = rhs;
   a.vec32 = vec32;
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
+  // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
+  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5))) {
+    const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !(g_stencil_site & 4));
+    if (rc != SITE_DECLINED) return rc;
+  }
   a.hr = d->Lx / 2;
   a.Ly = d->Ly;
   a.half_vol = (long)a.hr * d->Ly;

@@ -449,9 +449,10 @@ struct BatchKcycle {
   }
   // complex<float> shadows of every level's matrices and null vectors, for the QMG_C32 K-cycle (the fp64 hierarchy stays
   // the master copy; call again after the hierarchy changes)
-  bool enable_f32_hierarchy() {
+  // half_fine: the fine level (nc = 2) additionally keeps its matrices in 16 bits for the K-cycle's own applies (112 B/site)
+  bool enable_f32_hierarchy(bool half_fine = false) {
     const int nl = mg->get_num_levels();
-    for (int i = 0; i < nl; i++) if (!mg->get_stencil(i) || !mg->get_stencil(i)->enable_f32_shadow()) return false;
+    for (int i = 0; i < nl; i++) if (!mg->get_stencil(i) || !mg->get_stencil(i)->enable_f32_shadow(half_fine && i == 0)) return false;
     for (int i = 0; i < nl - 1; i++) if (!mg->get_transfer(i)->enable_f32_shadow()) return false;
     return true;
   }

@@ -96,7 +96,12 @@ struct Stencil2D {
   // fp32 shadow (qmg_dtype QMG_C32; not in the reference, which is fp64 only): complex<float> copies of the arrays a
   // K-cycle level streams -- the ORIGINAL clover / hopping and, when built, the right-block-Jacobi hopping and cinv.
   // The fp64 arrays stay the master copy; enable_f32_shadow() (re)creates the copies from their current contents.
-  struct F32Shadow { void* clover; void* hopping; void* rbj_hopping; void* rbj_cinv; bool on; } f32;
+  struct F32Shadow {
+    void* clover; void* hopping; void* rbj_hopping; void* rbj_cinv; bool on;
+    // optional (nc = 2): complex<half> copies of the matrices the smoother / residual applies of the fp32 K-cycle stream
+    // (qmg_stencil_apply_h16: 112 B/site); cinv stays fp32 (it is applied once per cycle)
+    void* clover16; void* hopping16; void* rbj_hopping16; bool half_on;
+  } f32;
   enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2 };
 
   bool built_dagger;
@@ -129,6 +134,7 @@ struct Stencil2D {
     eo_cvector = 0;
     f32_matrices = false; clover32 = hopping32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
+    f32.clover16 = f32.hopping16 = f32.rbj_hopping16 = 0; f32.half_on = false;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
     built_rbj_dagger = false; rbj_dagger_clover = rbj_dagger_hopping = rbj_dagger_twolink = rbj_dagger_corner = rbj_dagger_cinv = 0;
@@ -147,8 +153,9 @@ struct Stencil2D {
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
   }
 
-  bool enable_f32_shadow() {
+  bool enable_f32_shadow(bool half_matrices = false) {
     disable_f32_shadow();
+    if (half_matrices && lat->get_nc() != 2) half_matrices = false;   // the 16-bit kernel serves nc = 2 (the fine Wilson-type operators)
     auto dup = [&](void** dst, const complex<double>* src, long n) -> bool {
       if (src == 0) return true;
       if (qmg_malloc(dst, (size_t)n * 8) != QMG_SUCCESS) { *dst = 0; return false; }
@@ -158,14 +165,24 @@ struct Stencil2D {
     if (swap_dagger || swap_rbjacobi || swap_rbj_dagger) { std::cout << "[QMG-ERROR]: enable_f32_shadow called while a stencil variant is swapped in.\n"; return false; }
     bool good = dup(&f32.clover, clover, lat->get_size_cm_l()) && dup(&f32.hopping, hopping, lat->get_size_hopping_l());
     if (good && built_rbjacobi) good = dup(&f32.rbj_hopping, rbjacobi_hopping, lat->get_size_hopping_l()) && dup(&f32.rbj_cinv, rbjacobi_cinv, lat->get_size_cm_l());
+    if (good && half_matrices) {
+      auto dup16 = [&](void** dst, const complex<double>* src, long n) -> bool {
+        if (src == 0) return true;
+        if (qmg_malloc(dst, (size_t)n * 4) != QMG_SUCCESS) { *dst = 0; return false; }
+        return qmg::ok(qmg_convert_to_c16(*dst, src, QMG_C64, (size_t)n, qmg::current_stream()), "qmg_convert_to_c16");
+      };
+      good = dup16(&f32.clover16, clover, lat->get_size_cm_l()) && dup16(&f32.hopping16, hopping, lat->get_size_hopping_l());
+      if (good && built_rbjacobi) good = dup16(&f32.rbj_hopping16, rbjacobi_hopping, lat->get_size_hopping_l());
+      f32.half_on = good;
+    }
     if (!good) { disable_f32_shadow(); return false; }
     f32.on = true;
     return true;
   }
   void disable_f32_shadow() {
-    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv};
+    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv, &f32.clover16, &f32.hopping16, &f32.rbj_hopping16};
     for (auto p : all) if (*p) { qmg_free(*p); *p = 0; }
-    f32.on = false;
+    f32.on = false; f32.half_on = false;
   }
 
   // Opt-in storage format for operators that only PRECONDITION (a K-cycle inside a flexible fp64 outer solver): keep a
@@ -335,6 +352,12 @@ struct Stencil2D {
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
     if (sizeof(T) == sizeof(float)) {
       if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
+      if (f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices, fp32 vectors
+        d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
+        d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
+        qmg::ok(qmg_stencil_apply_h16(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_h16");
+        return;
+      }
       d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
       d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
       qmg::ok(qmg_stencil_apply_t(QMG_C32, &d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_t");

@@ -205,3 +205,56 @@ def test_fp32_kcycle_preconditions_the_fp64_solve(golden_dir, args, extra):
         assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-1500:]
         its[tag] = [int(r[1]) for r in rows]
     assert all(abs(a - b) <= 2 for a, b in zip(its["f64"], its["f32"])), its
+
+
+HALF_PIECES = [("all_zero", ol.P_ALL | ol.P_ZERO), ("all_accumulate", ol.P_ALL), ("eo_inplace_like", ol.P_EO | ol.P_ZERO_E), ("oe", ol.P_OE), ("clover_shift_o", ol.P_CLOVER_O | ol.P_SHIFT_O | ol.P_ZERO_O),
+               ("dir_ym1_both", (ol.P_EO_XP1 << 3) | (ol.P_OE_XP1 << 3))]
+
+
+@pytest.mark.parametrize("name,pieces", HALF_PIECES)
+@pytest.mark.parametrize("Lx,Ly", [(32, 32), (6, 4), (520, 10)])
+def test_fine_apply_with_16_bit_stored_matrices(name, pieces, Lx, Ly):
+    """qmg_stencil_apply_h16: complex<half> matrices, complex<float> vectors, fp32 arithmetic, one lane per site.
+    Against the fp64 oracle applied to the SAME matrices after rounding to half and the same fp32 vectors: 5e-6."""
+    nc, vol = 2, Lx * Ly
+    h16 = lambda v: (v.real.astype(np.float16).astype(np.float64) + 1j * v.imag.astype(np.float16).astype(np.float64))
+    clover, hopping = h16(cs.gaussian_cvec(vol * 4, 1)), h16(cs.gaussian_cvec(4 * vol * 4, 2))
+    rhs, lhs0 = r32(cs.gaussian_cvec(vol * nc, 3)), r32(cs.gaussian_cvec(vol * nc, 4))
+    shifts = (0.3 - 0.1j, 0.05 + 0.02j, -0.07j)
+    want = ol.stencil_apply(ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts), rhs, pieces, lhs=lhs0.copy())
+    dc64, dh64 = qmg.DeviceArray.from_host(clover), qmg.DeviceArray.from_host(hopping)
+    dc, dh = qmg.DeviceArray(vol * 4, np.float32), qmg.DeviceArray(4 * vol * 4, np.float32)      # 4 bytes per complex<half>
+    qmg.convert_to_c16(dc, dc64, qmg.C64, vol * 4)
+    qmg.convert_to_c16(dh, dh64, qmg.C64, 4 * vol * 4)
+    dr, dl = D32(rhs), D32(lhs0)
+    qmg.stencil_apply_h16(qmg.make_desc(Lx, Ly, nc, dc, dh, *shifts), dl, dr, pieces)
+    assert cs.rel_l2(H(dl), want) < TOL32
+    # masked batch: system 1 of 3 frozen
+    size = vol * nc
+    rb, lb = r32(cs.gaussian_cvec(3 * size, 5)), r32(cs.gaussian_cvec(3 * size, 6))
+    drb, dlb = D32(rb), D32(lb)
+    qmg.stencil_apply_h16(qmg.make_desc(Lx, Ly, nc, dc, dh, *shifts), dlb, drb, ol.P_ALL | ol.P_ZERO, nrhs=3, vec_stride=size, mask=0b101)
+    got = H(dlb)
+    for k in range(3):
+        seg = slice(k * size, (k + 1) * size)
+        if k == 1:
+            assert np.array_equal(got[seg], lb[seg])
+        else:
+            assert cs.rel_l2(got[seg], ol.stencil_apply(ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts), rb[seg].copy())) < TOL32
+
+
+@pytest.mark.parametrize("variant", ["", "schur"])
+def test_kcycle_with_16_bit_fine_matrices_still_reaches_fp64_tolerance(golden_dir, variant):
+    """QMG_F16_FINE=1: inside the fp32 K-cycle the level-0 matrices are streamed in 16 bits (operator perturbed by ~5e-4);
+    the fp64 outer VPGCR still converges to 1e-10 (true residual of the ORIGINAL fp64 operator) in about the same count."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    its = {}
+    for tag, env in (("f32", {}), ("f16", {"QMG_F16_FINE": "1"})):
+        cmd = [os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "2", "1", gauge_file, "64", "nrhs=2", "f32"] + ([variant] if variant else [])
+        out = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert ("stored in 16 bits" in out.stdout) == (tag == "f16")
+        rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+        assert len(rows) == 2 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-1500:]
+        its[tag] = [int(r[1]) for r in rows]
+    assert all(b <= a + max(3, a // 8) for a, b in zip(its["f32"], its["f16"])), its

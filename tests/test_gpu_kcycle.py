@@ -119,7 +119,8 @@ def test_n13_128_nc12_stagnation_is_a_property_of_the_configuration(golden_dir):
     """`n13_wilson_kcycle 128 -0.07 6.0 1 12` on the reference's l128t128b60 fixture does not converge (1.2e-4 after 1000
     iterations).  It is not a defect of the nc = 12 path: at mass -0.07 this configuration is past critical (a negative
     real eigenvalue, tests/test_oracle_known_answers.py::test_l128_fixture_is_past_critical_at_mass_minus_007), and the
-    CPU oracle's K-cycle on the SAME null vectors stagnates the same way -- outer residual histories agree to 1e-6 and
+    CPU oracle's K-cycle on the SAME null vectors stagnates the same way -- outer residual histories agree to 1e-5 (the
+    first three to 1e-7; once the coarsest solves run into their cap the history amplifies summation-order rounding) and
     the coarsest GCR takes the same number of iterations call by call (18, 125, then the 1000-iteration cap)."""
     L, nit = 128, 8
     gauge_file = os.path.join(golden_dir, "l128t128b60_heatbath.dat")
@@ -135,7 +136,7 @@ def test_n13_128_nc12_stagnation_is_a_property_of_the_configuration(golden_dir):
     gauge = ol.phases_to_gauge_u1(np.loadtxt(gauge_file), L, L)
     it, _, _, _, _, hist, chist = ol.wilson_kcycle_history(L, -0.07, 1, 12, gauge, nullvecs, b, max_iter=nit)
     assert it < 0 and len(hist) == nit
-    assert np.allclose(gpu_hist, hist, rtol=1e-6), (gpu_hist, list(hist))
+    assert np.allclose(gpu_hist[:3], hist[:3], rtol=1e-7) and np.allclose(gpu_hist, hist, rtol=1e-5), (gpu_hist, list(hist))
     assert hist[-1] > 5e-3 and hist[-1] / hist[-2] > 0.99            # stagnating, in both
     # the coarsest solves: same iteration counts while they converge, and both hit the cap from the third call on
     assert [c for c in gpu_coarsest[:2]] == [(True, int(chist[0])), (True, int(chist[1]))]

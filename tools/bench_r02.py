@@ -73,6 +73,15 @@ if want("fine"):
             ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
             row("k_stencil_pair<float,2,2> Wilson %d^2 fp32 (stencil_nt=%d)" % (L, nt), ms, 192 * vol, "192 B/site: fp32 matrices AND vectors, fp32 arithmetic")
         qmg.set_tuning("stencil_nt", 3)
+        c16, h16 = qmg.DeviceArray(4 * vol, np.float32), qmg.DeviceArray(16 * vol, np.float32)
+        qmg.convert_to_c16(c16, wl.clover, qmg.C64, 4 * vol)
+        qmg.convert_to_c16(h16, wl.hopping, qmg.C64, 16 * vol)
+        d16 = qmg.make_desc(L, L, 2, c16, h16, bench.MASS)
+        ms = timeit(lambda: qmg.stencil_apply_h16(d16, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
+        row("k_stencil_h16 Wilson %d^2, complex<half> matrices + complex<float> vectors" % L, ms, 112 * vol, "112 B/site: 16-bit stored operator (preconditioner only)")
+        ms = timeit(lambda: qmg.stencil_apply_h16(d16, l32, r32, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
+        row("k_stencil_h16 D_eo %d^2" % L, ms, (4 * 16 + 16 + 16) * vol / 2, "one parity")
+        c16.free(); h16.free()
         # one-parity (Schur) applies
         ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
         row("k_stencil_elem<float,2> D_eo %d^2 fp32" % L, ms, (4 * 32 + 16 + 16) * vol / 2, "one parity: 4 hopping matrices + rhs + lhs")
