@@ -309,6 +309,11 @@ int qmg_comm_finalize(void);
  *   "gen_sites"     cap on sites per block of kernel B, 0 = register-limited maximum (0)
  *   "gen32"         fp32-stored matrices, even nc: 1 = fp32 tile end to end (kernel B32), 2 = same with 2-site tiles,
  *                   0 = kernel B with widening loads (1)
+ *   "stencil_site"  nc = 2 through the site kernel (csrc/qmg_site.hip): bit 0 fp64 where it is the faster one (hops-only,
+ *                   one system), bit 1 fp32, bit 2 fp64 always (A/B measurements) (3)
+ *   "site_block"    threads per block of the site kernel: 64, 128 or 256 (256); "site_gy": cap on its grid.y, 0 = rows (0);
+ *                   "site_generic": 1 = its run-time-flag variant instead of the compile-time piece shapes (0)
+ *   "mfma_vl"       kernel C: right-hand sides through an LDS slice (coalesced loads / stores) (1)
  *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
  *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);
  *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)

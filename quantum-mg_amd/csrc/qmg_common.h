@@ -174,7 +174,7 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
 
 extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
 extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
-extern int g_site_block, g_site_gy;   // qmg_site.hip; "site_block", "site_gy"
+extern int g_site_block, g_site_gy, g_site_generic;   // qmg_site.hip; "site_block", "site_gy", "site_generic"
 
 // Memory-bound 1-D launches.  One 16-byte element per thread up to 2^18 blocks, grid-stride beyond: on this part a
 // streaming copy reaches 6.2 TB/s at 262 144 blocks but only 5.4 TB/s at 8 192 (profiles/r01_membw_ceiling.txt).

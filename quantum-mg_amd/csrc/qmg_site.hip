@@ -205,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void k_to_half(__half2* __restrict__ dst, co
 }
 
 int g_site_block = BLOCK, g_site_gy = 0;
-static int g_site_generic = 0;   // diagnostics: 1 forces the run-time-flag kernel (SHAPE 0)
+int g_site_generic = 0;   // "site_generic": 1 forces the run-time-flag kernel (SHAPE 0)
 
 template <int ST, bool BATCH>
 static void launch_site_b(const SiteArgs& a, int shape, bool zero, dim3 grid, hipStream_t st) {
@@ -274,8 +274,6 @@ int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const v
 using namespace qmg;
 
 extern "C" {
-
-int qmg_site_force_generic(int on) { g_site_generic = on ? 1 : 0; return QMG_SUCCESS; }
 
 // complex<double> or complex<float> (src_dtype) -> complex<half>, round to nearest
 int qmg_convert_to_c16(void* dst_c16, const void* src, int src_dtype, size_t n, void* stream) {

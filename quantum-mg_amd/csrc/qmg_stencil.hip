@@ -1092,6 +1092,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_site")) { g_stencil_site = value; return QMG_SUCCESS; }
   if (!strcmp(key, "site_block")) { if (value != 64 && value != 128 && value != 256) return QMG_ERR_INVALID; g_site_block = value; return QMG_SUCCESS; }
   if (!strcmp(key, "site_gy")) { g_site_gy = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "site_generic")) { g_site_generic = value ? 1 : 0; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_rows")) { g_stencil_rows = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen_sites")) { g_gen_sites = value; return QMG_SUCCESS; }
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }

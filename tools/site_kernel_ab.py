@@ -1,5 +1,5 @@
 """A/B of the nc = 2 site kernel (csrc/qmg_site.hip) against kernel A at 4096^2 in the three storage precisions.
-   python tools/h16_shapes.py     (GPU box)"""
+   python tools/site_kernel_ab.py     (GPU box)"""
 import importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
@@ -39,7 +39,7 @@ for site in (0, 1):
     run(lambda: qmg.stencil_apply_t(qmg.C32, d32, l, r, DEO), (128 + 32) * vol / 2, "fp32 D_eo  site=%d" % site)
 d16 = qmg.make_desc(L, L, 2, c16, h16, -0.07)
 for gen in (0, 1):
-    qmg.lib().qmg_site_force_generic(gen)
+    qmg.set_tuning("site_generic", gen)
     run(lambda: qmg.stencil_apply_h16(d16, l, r, FULL), 112 * vol, "16-bit matrices full  generic=%d" % gen)
     run(lambda: qmg.stencil_apply_h16(d16, l, r, DEO), (64 + 32) * vol / 2, "16-bit matrices D_eo  generic=%d" % gen)
 
