@@ -298,6 +298,25 @@ int qmg_comm_world(int* world, int* rank);
 int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream);   /* in place, async; no-op when world == 1 */
 int qmg_comm_finalize(void);
 
+/* ---------------- y-slab domain decomposition of ONE lattice ----------------
+ * The reference is single-process and marks where this goes: cshift/cshift_2d.h:39-42,72,89 ("Becomes MPI").  Rank r of R
+ * holds rows [r Ly/R, (r+1) Ly/R) of the global lattice as an ordinary even-odd lattice of Ly/R rows (Ly/R even, so the
+ * colouring of a slab is the global one); every array keeps the layout of section 3.  Three pieces:
+ *   qmg_halo_exchange         first / last row of a vector -> the neighbouring ranks' halo buffers (RCCL send/recv on xGMI;
+ *                             one rank: device copies = the periodic wrap).  Halo buffer: [system][parity][Lx/2][nc] complex.
+ *   qmg_stencil_apply_slab    the apply with rows -1 / Ly read from the halo buffers; `rows` splits it into the interior
+ *                             (no halo needed: overlaps the exchange) and the two boundary rows.  nc = 2 in this round.
+ *   qmg_comm_set_distributed_reductions   reductions of slab vectors are summed over the ranks inside the library.
+ * Stencil arrays of a slab: qmg_wilson_fill_slab from the global gauge field (32 B/site, replicated). */
+#define QMG_SLAB_H16 0x100   /* or-ed into the storage argument: matrices stored as complex<half> (vectors QMG_C32) */
+int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly_local, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
+                      size_t halo_stride, void* stream);
+int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi,
+                           unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows, void* stream);
+int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, double wilson_coeff,
+                         void* stream);
+int qmg_comm_set_distributed_reductions(int on);
+
 /* ---------------- tuning hooks (not part of the reference surface) ---------------- */
 /* Dispatch / codegen knobs, all with the defaults the measurements in profiles/ chose; results never depend on them
  * beyond summation order.  Unknown keys return QMG_ERR_INVALID.

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_stencil_apply_h16",
+    "qmg_halo_exchange", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -469,6 +470,27 @@ def stencil_apply_h16(desc, lhs, rhs, pieces, nrhs=1, vec_stride=0, mask=1, stre
 
 def comm_init_env(world, rank):
     check(lib().qmg_comm_init_env(world, rank), "qmg_comm_init_env")
+
+
+SLAB_H16 = 0x100
+
+
+def halo_exchange(dtype, vec, Lx, Ly_local, nc, halo_lo, halo_hi, nrhs=1, vec_stride=0, halo_stride=0, stream=None):
+    check(lib().qmg_halo_exchange(dtype, _vp(vec), Lx, Ly_local, nc, _vp(halo_lo), _vp(halo_hi), nrhs, C.c_size_t(vec_stride), C.c_size_t(halo_stride), stream),
+          "qmg_halo_exchange")
+
+
+def stencil_apply_slab(storage, desc, lhs, rhs, halo_lo, halo_hi, pieces, nrhs=1, vec_stride=0, halo_stride=0, mask=1, rows=0, stream=None):
+    check(lib().qmg_stencil_apply_slab(storage, C.byref(desc), _vp(lhs), _vp(rhs), _vp(halo_lo), _vp(halo_hi), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride),
+                                       C.c_size_t(halo_stride), C.c_uint(mask), rows, stream), "qmg_stencil_apply_slab")
+
+
+def wilson_fill_slab(clover, hopping, gauge_global, Lx, Ly_global, y0, Ly_local, w=1.0, stream=None):
+    check(lib().qmg_wilson_fill_slab(_vp(clover), _vp(hopping), _vp(gauge_global), Lx, Ly_global, y0, Ly_local, C.c_double(w), stream), "qmg_wilson_fill_slab")
+
+
+def comm_set_distributed_reductions(on):
+    check(lib().qmg_comm_set_distributed_reductions(1 if on else 0), "qmg_comm_set_distributed_reductions")
 
 
 def comm_all_ok(ok):

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_breduce_final(const double* __restric
 struct BatchWorkspace {
   double* partials = nullptr;   // BATCH_MAX * BRED_BLOCKS * 2 * BDOT_MAX doubles (8 MiB)
   double* pinned = nullptr;     // host-pinned, device-visible results: BATCH_MAX * 2 * BDOT_MAX doubles
+  double* result = nullptr;     // the same in HBM: where the results go when they are summed over ranks first
   int device = -1;
 };
 static thread_local BatchWorkspace g_bws;
@@ -197,6 +198,8 @@ static int get_bws(BatchWorkspace** out) {
   if (g_bws.device != dev) {
     QMG_HIP_CHECK(hipMalloc((void**)&g_bws.partials, sizeof(double) * BATCH_MAX * BRED_BLOCKS * 2 * BDOT_MAX));
     QMG_HIP_CHECK(hipHostMalloc((void**)&g_bws.pinned, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX, hipHostMallocDefault));
+    QMG_HIP_CHECK(hipMalloc((void**)&g_bws.result, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
+    QMG_HIP_CHECK(hipMemset(g_bws.result, 0, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
     g_bws.device = dev;
   }
   *out = &g_bws;
@@ -318,8 +321,16 @@ int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n
   QMG_DISPATCH_TW(dtype, W, QMG_K);
 #undef QMG_K
   QMG_LAUNCH_CHECK();
-  k_breduce_final<<<dim3(2, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2, bi, 2, ws->pinned);
+  // slabs of one lattice: the per-system results are summed over the ranks before they reach the host (every rank has
+  // the same active mask: the lock-step decisions are taken on these very sums)
+  const bool dist = dist_reductions_on();
+  k_breduce_final<<<dim3(2, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2, bi, 2, dist ? ws->result : ws->pinned);
   QMG_LAUNCH_CHECK();
+  if (dist) {
+    rc = dist_allreduce(ws->result, 2 * nrhs, false, st);
+    if (rc) return rc;
+    QMG_HIP_CHECK(hipMemcpyAsync(ws->pinned, ws->result, sizeof(double) * 2 * nrhs, hipMemcpyDeviceToHost, st));
+  }
   QMG_HIP_CHECK(hipStreamSynchronize(st));
   for (int s = 0; s < bi.n; s++) { out_host[2 * bi.id[s]] = ws->pinned[2 * bi.id[s]]; out_host[2 * bi.id[s] + 1] = ws->pinned[2 * bi.id[s] + 1]; }
   return QMG_SUCCESS;
@@ -360,8 +371,14 @@ int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y
     j0 += kt;
     QMG_LAUNCH_CHECK();
   }
-  k_breduce_final<<<dim3(2 * nj, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2 * nj, bi, 2 * nj, ws->pinned);
+  const bool dist = dist_reductions_on();
+  k_breduce_final<<<dim3(2 * nj, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2 * nj, bi, 2 * nj, dist ? ws->result : ws->pinned);
   QMG_LAUNCH_CHECK();
+  if (dist) {
+    rc = dist_allreduce(ws->result, 2 * nj * nrhs, false, st);
+    if (rc) return rc;
+    QMG_HIP_CHECK(hipMemcpyAsync(ws->pinned, ws->result, sizeof(double) * 2 * nj * nrhs, hipMemcpyDeviceToHost, st));
+  }
   QMG_HIP_CHECK(hipStreamSynchronize(st));
   for (int s = 0; s < bi.n; s++)
     memcpy(out_host + (size_t)bi.id[s] * 2 * nj, ws->pinned + (size_t)bi.id[s] * 2 * nj, sizeof(double) * 2 * nj);

@@ -252,10 +252,12 @@ static int reduce2(const void* x, const void* y, size_t n, int width, double* ou
   const unsigned g = red_grid((long)n);
   k_reduce<OP><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
   QMG_LAUNCH_CHECK();
-  double* res = out_dev ? out_dev : ws->pinned;
+  const bool dist = dist_reductions_on();   // slabs of one lattice: sum (max) over the ranks before the value leaves HBM
+  double* res = out_dev ? out_dev : (dist ? ws->result : ws->pinned);
   if (OP == RED_NORMINF) k_reduce_final<true, true><<<width, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
   else k_reduce_final<false, false><<<width, BLOCK, 0, st>>>(ws->partials, (int)g, 2, width, res);
   QMG_LAUNCH_CHECK();
+  if (dist) { rc = dist_allreduce(res, width, OP == RED_NORMINF, st); if (rc) return rc; }
   return finish(res, width, nullptr, out_host, st);
 }
 
@@ -377,9 +379,11 @@ int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* 
     else { k_multidot<1><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 1; }
     QMG_LAUNCH_CHECK();
   }
-  double* res = out_dev ? out_dev : ws->pinned;
+  const bool dist = dist_reductions_on();
+  double* res = out_dev ? out_dev : (dist ? ws->result : ws->pinned);
   k_reduce_final<false, false><<<2 * k, BLOCK, 0, st>>>(ws->partials, (int)g, 2 * k, 2 * k, res);
   QMG_LAUNCH_CHECK();
+  if (dist) { rc = dist_allreduce(res, 2 * k, false, st); if (rc) return rc; }
   return finish(res, 2 * k, nullptr, out_host, st);
 }
 

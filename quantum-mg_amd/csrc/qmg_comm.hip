@@ -1,8 +1,11 @@
-// qmg_comm.hip -- the one collective the path needs: a sum all-reduce of a small double vector
-// (per-right-hand-side residual norms / inner products) over RCCL on xGMI, so that ranks holding
-// different right-hand sides take the same convergence / restart decision.
-// Messages are <= a few KiB: latency-bound; callers fuse every reduction of a Krylov step into ONE
-// buffer and call this once per step.
+// qmg_comm.hip -- the two exchanges the path has, over RCCL on xGMI:
+//   * a sum all-reduce of a small double vector (per-right-hand-side residual norms / inner products), so that ranks
+//     holding different right-hand sides take the same convergence / restart decision.  Messages are <= a
+//     few KiB: latency-bound; callers fuse every reduction of a Krylov step into ONE buffer and call this once per step;
+//   * the halo rows of a y-slab decomposition of ONE lattice (the reference marks the spot:
+//     cshift/cshift_2d.h:39-42,72,89 "Becomes MPI"): point-to-point send / recv of the first and last row of a slab to
+//     the two neighbouring ranks -- xGMI is point-to-point, so this is its natural pattern (qmg_halo_exchange), plus
+//     the "distributed reductions" switch that makes every reduction entry point of the library sum over ranks.
 //
 // Types and enumerators come from <rccl/rccl.h>; the library itself is loaded lazily with dlopen so that
 // single-GPU users (and the CPU build check) do not need librccl at load time; the calls return
@@ -39,11 +42,16 @@ struct Rccl {
   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclGetErrorString) get_error_string = nullptr;
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool force = false;
+  bool dist_reduce = false;   // qmg_comm_set_distributed_reductions
   bool load() {
     if (handle) return true;
     handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -52,12 +60,25 @@ struct Rccl {
     get_unique_id = (decltype(get_unique_id))dlsym(handle, "ncclGetUniqueId");
     comm_init_rank = (decltype(comm_init_rank))dlsym(handle, "ncclCommInitRank");
     all_reduce = (decltype(all_reduce))dlsym(handle, "ncclAllReduce");
+    send = (decltype(send))dlsym(handle, "ncclSend");
+    recv = (decltype(recv))dlsym(handle, "ncclRecv");
+    group_start = (decltype(group_start))dlsym(handle, "ncclGroupStart");
+    group_end = (decltype(group_end))dlsym(handle, "ncclGroupEnd");
     comm_destroy = (decltype(comm_destroy))dlsym(handle, "ncclCommDestroy");
     get_error_string = (decltype(get_error_string))dlsym(handle, "ncclGetErrorString");
-    return get_unique_id && comm_init_rank && all_reduce && comm_destroy;
+    return get_unique_id && comm_init_rank && all_reduce && comm_destroy && send && recv && group_start && group_end;
   }
 };
 static Rccl g_rccl;
+
+// For the reduction entry points (qmg_blas.hip, qmg_batch.hip): with distributed reductions on and more than one rank
+// (or the forced 1-rank communicator of the tests), sum (or max) `n` doubles in HBM over the ranks, in place, on `st`.
+bool dist_reductions_on() { return g_rccl.dist_reduce && g_rccl.comm && (g_rccl.world > 1 || g_rccl.force); }
+int dist_allreduce(double* buf_dev, int n, bool op_max, hipStream_t st) {
+  if (!dist_reductions_on() || n == 0) return QMG_SUCCESS;
+  if (g_rccl.all_reduce(buf_dev, buf_dev, (size_t)n, ncclDouble, op_max ? ncclMax : ncclSum, g_rccl.comm, st) != ncclSuccess) return QMG_ERR_HIP;
+  return QMG_SUCCESS;
+}
 
 static_assert(sizeof(ncclUniqueId) == 128, "the C-ABI ships the RCCL id as 128 bytes");
 
@@ -239,9 +260,62 @@ int qmg_comm_all_ok(int ok, int* all_ok) {
   return QMG_SUCCESS;
 }
 
+// on != 0: every host- or device-returning reduction of the library (norm2sq, dot, diffnorm2sq, norminf, multidot and the
+// batch reductions) returns the sum (max for norminf) over all ranks -- the vectors are slabs of one lattice.  Off (the
+// default): reductions are local, as for ranks that hold different right-hand sides.  Needs an initialised communicator.
+int qmg_comm_set_distributed_reductions(int on) {
+  if (on && !g_rccl.comm && (g_rccl.world > 1 || g_rccl.force)) return QMG_ERR_INVALID;
+  g_rccl.dist_reduce = on != 0;
+  return QMG_SUCCESS;
+}
+
+// Halo rows of a y-slab: this rank holds rows [y0, y0 + Ly) of the lattice in the usual even-odd layout (Ly even, so the
+// colouring of a slab is the global one).  For each of the nrhs vectors, the slab's LAST row (both parities) goes to rank+1,
+// which receives it as its halo_lo (its row "-1"), and the FIRST row goes to rank-1 as that rank's halo_hi (its row "Ly").
+// Rows are contiguous in the layout, so they are sent straight out of the vector: no pack kernel.
+//   halo layout: [system][parity q of the halo row's sites][hr][nc] complex; halo_stride elements between systems.
+// Periodic in y over the ranks; with one rank (no communicator) the rows are copied on the device -- the same wrap the
+// single-domain kernels do by index.  Asynchronous on `stream`.
+int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
+                      size_t halo_stride, void* stream) {
+  if (!valid_dtype(dtype) || !vec || !halo_lo || !halo_hi || !valid_lattice(Lx, Ly) || nc < 1 || nrhs < 1) return QMG_ERR_INVALID;
+  const size_t esz = dtype_size(dtype);
+  const size_t row = (size_t)(Lx / 2) * nc;                 // complex elements of one parity's row
+  const size_t half = row * (size_t)Ly;
+  if (nrhs > 1 && (vec_stride < 2 * half || halo_stride < 2 * row)) return QMG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  const bool rccl = g_rccl.comm && (g_rccl.world > 1 || g_rccl.force);
+  const int up = (g_rccl.rank + 1) % g_rccl.world, down = (g_rccl.rank + g_rccl.world - 1) % g_rccl.world;
+  const ncclDataType_t unit = ncclChar;
+  if (rccl && g_rccl.group_start() != ncclSuccess) return QMG_ERR_HIP;
+  int rc = QMG_SUCCESS;
+  for (int k = 0; k < nrhs && rc == QMG_SUCCESS; k++) {
+    const char* v = (const char*)vec + (size_t)k * vec_stride * esz;
+    char* lo = (char*)halo_lo + (size_t)k * halo_stride * esz;
+    char* hi = (char*)halo_hi + (size_t)k * halo_stride * esz;
+    for (int q = 0; q < 2; q++) {
+      const char* first = v + ((size_t)q * half) * esz;                       // row y = 0 of parity q
+      const char* last = v + ((size_t)q * half + (size_t)(Ly - 1) * row) * esz;  // row y = Ly - 1
+      if (rccl) {
+        // order within the group: everything to / from `up` first, then `down`; with two ranks up == down and the
+        // matching is by order per peer, so sends and receives are issued in the same (last, first) order on both sides
+        if (g_rccl.send(last, row * esz, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.send(first, row * esz, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.recv(lo + (size_t)q * row * esz, row * esz, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.recv(hi + (size_t)q * row * esz, row * esz, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+      } else {
+        if (hipMemcpyAsync(lo + (size_t)q * row * esz, last, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
+        if (hipMemcpyAsync(hi + (size_t)q * row * esz, first, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
+      }
+    }
+  }
+  if (rccl && g_rccl.group_end() != ncclSuccess) return QMG_ERR_HIP;
+  return rc;
+}
+
 int qmg_comm_finalize(void) {
   if (g_rccl.comm) { g_rccl.comm_destroy(g_rccl.comm); g_rccl.comm = nullptr; }
-  g_rccl.world = 1; g_rccl.rank = 0; g_rccl.force = false;
+  g_rccl.world = 1; g_rccl.rank = 0; g_rccl.force = false; g_rccl.dist_reduce = false;
   return QMG_SUCCESS;
 }
 

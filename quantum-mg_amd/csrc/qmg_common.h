@@ -40,10 +40,15 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline bool valid_lattice(int Lx, int Ly) { return Lx >= 2 && Ly >= 2 && !(Lx & 1) && !(Ly & 1); }
 
+struct SlabHalo { const void* lo; const void* hi; long stride; int rows; };   // y-slab halos (qmg_stencil_apply_slab)
 // qmg_site.hip: nc = 2 apply; storage 0 = complex<half> matrices + complex<float> vectors, 1 = complex<float>, 2 = complex<double>
 int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride,
-                      const unsigned char* ridx, hipStream_t st, bool only_where_faster);
+                      const unsigned char* ridx, hipStream_t st, bool only_where_faster, const struct SlabHalo* slab);
 constexpr int SITE_DECLINED = 1000;   // not an error: the caller's own kernel is the better one for this launch
+
+// qmg_comm.hip: reductions of y-slab vectors are summed over the ranks (qmg_comm_set_distributed_reductions)
+bool dist_reductions_on();
+int dist_allreduce(double* buf_dev, int n, bool op_max, hipStream_t st);
 
 // ---------------- complex arithmetic (explicit FMAs; 8 flop per MAC) ----------------
 __device__ __forceinline__ cplx cmake(double re, double im) { return make_double2(re, im); }

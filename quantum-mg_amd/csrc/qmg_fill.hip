@@ -71,6 +71,39 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_fill(cplx* __restrict__ clover
   }
 }
 
+// The same for one y-slab (rows y0 .. y0 + Ly_loc - 1 of the global lattice, y0 even): the links are read from the GLOBAL
+// gauge field (32 B/site, every rank holds it), so the -y hop of the slab's first row gets the neighbour slab's link.
+__global__ __launch_bounds__(BLOCK) void k_wilson_fill_slab(cplx* __restrict__ clover, cplx* __restrict__ hop, const cplx* __restrict__ g,
+                                                            int hr, int Ly_g, int y0, int Ly_l, double w) {
+  const long hv_l = (long)hr * Ly_l, vol_l = 2 * hv_l, cm = vol_l * 4;
+  const long hv_g = (long)hr * Ly_g, vol_g = 2 * hv_g;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < vol_l; i += (long)gridDim.x * BLOCK) {
+    const int p = (int)(i / hv_l);
+    const long wi = i - (long)p * hv_l;
+    const int yl = (int)(wi / hr), j = (int)(wi - (long)yl * hr);
+    const int y = y0 + yl;
+    const long gi = (long)p * hv_g + (long)y * hr + j;
+    const cplx ux = g[gi], uy = g[vol_g + gi];
+    const cplx uxb = cconj(g[neighbour_site(QMG_CSHIFT_FROM_XM1, p, y, j, hr, Ly_g, hv_g)]);
+    const cplx uyb = cconj(g[vol_g + neighbour_site(QMG_CSHIFT_FROM_YM1, p, y, j, hr, Ly_g, hv_g)]);
+    const double hw = -0.5 * w;
+    cplx* c = clover + 4 * i;
+    c[0] = cmake(2.0 * w, 0.0); c[1] = cmake(0.0, 0.0); c[2] = cmake(0.0, 0.0); c[3] = cmake(2.0 * w, 0.0);
+    cplx* h = hop + 4 * i;
+    h[0] = cmake(hw * ux.x, hw * ux.y); h[1] = cmake(0.5 * ux.x, 0.5 * ux.y);
+    h[2] = h[1];                        h[3] = h[0];
+    h = hop + cm + 4 * i;
+    h[0] = cmake(hw * uy.x, hw * uy.y); h[1] = cmake(0.5 * uy.y, -0.5 * uy.x);
+    h[2] = cmake(-0.5 * uy.y, 0.5 * uy.x); h[3] = h[0];
+    h = hop + 2 * cm + 4 * i;
+    h[0] = cmake(hw * uxb.x, hw * uxb.y); h[1] = cmake(-0.5 * uxb.x, -0.5 * uxb.y);
+    h[2] = h[1];                          h[3] = h[0];
+    h = hop + 3 * cm + 4 * i;
+    h[0] = cmake(hw * uyb.x, hw * uyb.y); h[1] = cmake(-0.5 * uyb.y, 0.5 * uyb.x);
+    h[2] = cmake(0.5 * uyb.y, -0.5 * uyb.x); h[3] = h[0];
+  }
+}
+
 // ---- Staggered2D (staggered.h:50-72; eta_y = 1 - 2 (x % 2), :253-259) and GaugedLaplace2D (gaugedlaplace.h:45-68) ----
 // mode 0: staggered (hopping only) ; mode 1: gauged Laplace (clover = 4, hopping = -U)
 __global__ __launch_bounds__(BLOCK) void k_nc1_fill(cplx* __restrict__ clover, cplx* __restrict__ hop,
@@ -290,6 +323,15 @@ int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, in
 int qmg_wilson_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, double w, void* stream) {
   if (!clover || !hopping || !gauge || !valid_lattice(Lx, Ly)) return QMG_ERR_INVALID;
   k_wilson_fill<<<grid_1d((size_t)Lx * Ly), BLOCK, 0, as_stream(stream)>>>((cplx*)clover, (cplx*)hopping, (const cplx*)gauge, Lx / 2, Ly, w);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, double w, void* stream) {
+  if (!clover || !hopping || !gauge_global || !valid_lattice(Lx, Ly_global) || !valid_lattice(Lx, Ly_local)) return QMG_ERR_INVALID;
+  if (y0 < 0 || (y0 & 1) || y0 + Ly_local > Ly_global) return QMG_ERR_INVALID;
+  k_wilson_fill_slab<<<grid_1d((size_t)Lx * Ly_local), BLOCK, 0, as_stream(stream)>>>((cplx*)clover, (cplx*)hopping, (const cplx*)gauge_global,
+                                                                                    Lx / 2, Ly_global, y0, Ly_local, w);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

@@ -42,6 +42,13 @@ struct SiteArgs {
   int par_first, par_count, nrows;
   double shift[2], eo_shift[2], dof_shift[2];
   int ridx[16];
+  // y-slab of a larger lattice (qmg_stencil_apply_slab): rows -1 and Ly of the right-hand side come from these buffers
+  // ([system][parity][hr] site vectors) instead of the periodic wrap; NULL = periodic in y
+  const void* halo_lo;
+  const void* halo_hi;
+  long halo_stride;        // complex elements between the systems of a halo buffer
+  int y_first, y_count;    // the rows of this launch: y_first .. y_first + y_count - 1 ...
+  int boundary_only;       // ... or, if set, the two boundary rows y = 0 and y = Ly - 1 (y_count = 2)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_site(const SiteArgs a) {
   const long sys_bytes = a.vec_stride * (long)(2 * sizeof(R));
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
-    const int y = (a.par_count == 2) ? (row >> 1) : row;
+    const int yi = (a.par_count == 2) ? (row >> 1) : row;
+    const int y = a.boundary_only ? (yi ? a.Ly - 1 : 0) : a.y_first + yi;
     const bool do_clover = SHAPE == 1 || (SHAPE == 0 && a.clover && ((a.pieces >> p) & 1u));
     const unsigned hop_mask = SHAPE ? 0xFu : (a.hopping ? ((a.pieces >> (2 + 4 * p)) & 0xFu) : 0u);
     const bool do_shift = (a.pieces >> (10 + p)) & 1u;
@@ -119,9 +127,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_site(const SiteArgs a) {
     auto load_x = [&](SiteX<NACC, R>& v, int k) {
       const long off = (long)a.ridx[k] * sys_bytes;
       const char* x = reinterpret_cast<const char*>(a.rhs) + off;
+      // a slab's rows -1 / Ly: the opposite-parity row of the halo buffer (row-uniform, so a scalar select)
+      const bool from_hi = a.halo_hi && y + 1 == a.Ly, from_lo = a.halo_lo && y == 0;
+      const long hoff = (long)a.ridx[k] * a.halo_stride * (long)(2 * sizeof(R));
+      const long hsite = (long)(1 - p) * a.hr + j;
 #pragma unroll
-      for (int d = 0; d < 4; d++)
-        if ((hop_mask >> d) & 1u) v.nb[d] = ld16(x, nb[d] * XCH + xc);
+      for (int d = 0; d < 4; d++) {
+        if (!((hop_mask >> d) & 1u)) continue;
+        if (d == 1 && from_hi) v.nb[d] = ld16(reinterpret_cast<const char*>(a.halo_hi) + hoff, hsite * XCH + xc);
+        else if (d == 3 && from_lo) v.nb[d] = ld16(reinterpret_cast<const char*>(a.halo_lo) + hoff, hsite * XCH + xc);
+        else v.nb[d] = ld16(x, nb[d] * XCH + xc);
+      }
       if (need_own) v.own = ld16(x, site * XCH + xc);
       if (!do_zero) {
         const char* o = reinterpret_cast<const char*>(a.lhs) + off;
@@ -225,7 +241,7 @@ static void launch_site(const SiteArgs& a, int shape, bool zero, dim3 grid, hipS
 // kernel A of qmg_stencil.hip does as well or better -- measured at 4096^2 (tools/h16_shapes.py): fp64 M 1.10 ms both,
 // fp64 batches of 8 0.63 ms (A) against 0.78 ms, fp64 D_eo 0.395 ms (site) against 0.425 ms.
 int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride,
-                      const unsigned char* ridx, hipStream_t st, bool only_where_faster) {
+                      const unsigned char* ridx, hipStream_t st, bool only_where_faster, const SlabHalo* slab) {
   if (d->nc != 2 || n < 1 || n > 16 || storage < 0 || storage > 2) return QMG_ERR_UNSUPPORTED;
   SiteArgs a;
   a.clover = d->clover; a.hopping = d->hopping; a.lhs = lhs; a.rhs = rhs;
@@ -243,7 +259,14 @@ int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const v
   if (!ev && !od) return QMG_SUCCESS;
   a.par_first = ev ? 0 : 1;
   a.par_count = (ev && od) ? 2 : 1;
-  a.nrows = d->Ly * a.par_count;
+  a.halo_lo = slab ? slab->lo : nullptr;
+  a.halo_hi = slab ? slab->hi : nullptr;
+  a.halo_stride = slab ? slab->stride : 0;
+  a.boundary_only = slab && slab->rows == 2;
+  a.y_first = (slab && slab->rows == 1) ? 1 : 0;
+  a.y_count = a.boundary_only ? 2 : (slab && slab->rows == 1) ? d->Ly - 2 : d->Ly;
+  if (a.y_count <= 0) return QMG_SUCCESS;
+  a.nrows = a.y_count * a.par_count;
   // the compile-time shape, if every processed parity asks for the same complete set
   int sh[2] = {0, 0};
   bool zero = true;
@@ -297,7 +320,30 @@ int qmg_stencil_apply_h16(const qmg_stencil_desc* d, void* lhs, const void* rhs,
   for (int k = 0; k < nrhs; k++)
     if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
   if (n == 0) return QMG_SUCCESS;
-  return site_kernel_apply(0, d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), false);
+  return site_kernel_apply(0, d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), false, nullptr);
+}
+
+// One y-slab of a lattice: lhs (+)= pieces(M) rhs on the slab's rows, the right-hand side's rows -1 / Ly taken from
+// halo_lo / halo_hi (filled by qmg_halo_exchange).  storage: QMG_C64, QMG_C32, or QMG_C32 | QMG_SLAB_H16 for 16-bit stored
+// matrices.  rows: 0 = all, 1 = interior rows only (need no halo: they can run while the exchange is in flight),
+// 2 = the two boundary rows.  nc = 2 only in this round (the fine Wilson-type operator): QMG_ERR_UNSUPPORTED otherwise.
+int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi,
+                           unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows, void* stream) {
+  if (!d || !lhs || !rhs || !halo_lo || !halo_hi || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2 || lhs == rhs) return QMG_ERR_INVALID;
+  if (!valid_lattice(d->Lx, d->Ly)) return QMG_ERR_INVALID;
+  const bool h16 = storage & QMG_SLAB_H16;
+  const int dtype = storage & ~QMG_SLAB_H16;
+  if (!valid_dtype(dtype) || (h16 && dtype != QMG_C32)) return QMG_ERR_INVALID;
+  if (d->nc != 2) return QMG_ERR_UNSUPPORTED;
+  if (nrhs > 1 && (vec_stride < (size_t)d->Lx * d->Ly * 2 || halo_stride < (size_t)d->Lx * 2)) return QMG_ERR_INVALID;
+  unsigned char ridx[16];
+  int n = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
+  if (n == 0) return QMG_SUCCESS;
+  SlabHalo slab;
+  slab.lo = halo_lo; slab.hi = halo_hi; slab.stride = (long)halo_stride; slab.rows = rows;
+  return site_kernel_apply(h16 ? 0 : (dtype == QMG_C32 ? 1 : 2), d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), false, &slab);
 }
 
 }  // extern "C"

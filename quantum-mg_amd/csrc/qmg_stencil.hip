@@ -1174,7 +1174,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
   if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5))) {
-    const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !(g_stencil_site & 4));
+    const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !(g_stencil_site & 4), nullptr);
     if (rc != SITE_DECLINED) return rc;
   }
   a.hr = d->Lx / 2;

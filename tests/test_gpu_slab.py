@@ -1,0 +1,181 @@
+"""y-slab domain decomposition of one lattice (csrc/qmg_site.hip, csrc/qmg_comm.hip, csrc/qmg_fill.hip).
+
+The reference is single-process (cshift/cshift_2d.h:39-42,72,89 only says "Becomes MPI"), so the pin is the path itself:
+a lattice cut into R slabs, each slab applied with its neighbours' boundary rows as halos, must reproduce the rows of the
+single-domain apply BIT FOR BIT (the per-site arithmetic is the same code).  One GPU box has one GPU, so the R slabs of
+these tests live in one process and the "exchange" between different slabs is done by the test; the library's own exchange
+is exercised on one rank (device copies = the periodic wrap) and through a real one-rank RCCL communicator
+(QMG_COMM_FORCE_RCCL: ncclSend / ncclRecv to self inside a group, and the all-reduce of the distributed reductions).
+More ranks need more GPUs: the driver's multi-GPU bench runs `also_slab_solve` (bench.py) on them."""
+import importlib
+
+import numpy as np
+import pytest
+
+import coordspace as cs
+
+qmg = importlib.import_module("quantum-mg_amd")
+pytestmark = pytest.mark.gpu
+D = qmg.DeviceArray.from_host
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    qmg.build()
+    qmg.init(0)
+    yield
+    qmg.sync()
+
+
+def rows(a, Ly, per_row, y0, n):
+    """rows y0 .. y0+n-1 of every (array, parity) plane of an even-odd array: a = [planes][2][Ly][per_row]"""
+    planes = a.size // (2 * Ly * per_row)
+    return a.reshape(planes, 2, Ly, per_row)[:, :, y0:y0 + n].reshape(-1).copy()
+
+
+def random_gauge(L, seed):
+    rng = np.random.default_rng(seed)
+    return np.exp(1j * rng.uniform(-np.pi, np.pi, size=2 * L * L))
+
+
+def to_storage(a, storage):
+    if storage == "c64":
+        return D(a)
+    if storage == "c32":
+        return D(a.astype(np.complex64))
+    d = qmg.DeviceArray(a.size, np.float32)           # complex<half>: 4 bytes per element
+    qmg.convert_to_c16(d, D(a), qmg.C64, a.size)
+    return d
+
+
+STORAGE = {"c64": (qmg.C64, np.complex128), "c32": (qmg.C32, np.complex64), "h16": (qmg.C32 | qmg.SLAB_H16, np.complex64)}
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_slab_fill_equals_the_rows_of_the_global_fill(R):
+    L = 32
+    g = D(random_gauge(L, 3))
+    cl, hp = qmg.DeviceArray(4 * L * L), qmg.DeviceArray(16 * L * L)
+    qmg.wilson_fill(cl, hp, g, L, L, 1.0)
+    cl_h, hp_h = cl.to_host(), hp.to_host()
+    Ll = L // R
+    for r in range(R):
+        c, h = qmg.DeviceArray(4 * L * Ll), qmg.DeviceArray(16 * L * Ll)
+        qmg.wilson_fill_slab(c, h, g, L, L, r * Ll, Ll, 1.0)
+        assert np.array_equal(c.to_host(), rows(cl_h, L, (L // 2) * 4, r * Ll, Ll))
+        assert np.array_equal(h.to_host(), rows(hp_h, L, (L // 2) * 4, r * Ll, Ll))
+    import ctypes as C
+    assert qmg.lib().qmg_wilson_fill_slab(C.c_void_p(cl.ptr), C.c_void_p(hp.ptr), C.c_void_p(g.ptr), L, L, 3, Ll, C.c_double(1.0), None) == 1   # odd y0
+
+
+def single_domain_apply(storage, L, cl, hp, x, pieces, lhs0, nrhs, mask, shifts):
+    dtype, vt = STORAGE[storage]
+    dc, dh = to_storage(cl, storage), to_storage(hp, storage)
+    d = qmg.make_desc(L, L, 2, dc, dh, *shifts)
+    dx, dl = D(x.astype(vt)), D(lhs0.astype(vt))
+    n = 2 * L * L
+    if storage == "h16":
+        qmg.stencil_apply_h16(d, dl, dx, pieces, nrhs, n, mask)
+    elif storage == "c32":
+        qmg.stencil_apply_t(qmg.C32, d, dl, dx, pieces, nrhs, n, mask)
+    else:
+        qmg.set_tuning("stencil_site", 7)             # the same kernel as the slab path, so the comparison is bit for bit
+        qmg.stencil_apply_t(qmg.C64, d, dl, dx, pieces, nrhs, n, mask)
+        qmg.set_tuning("stencil_site", 3)
+    return dl.to_host()
+
+
+@pytest.mark.parametrize("storage", ["c64", "c32", "h16"])
+@pytest.mark.parametrize("R,split", [(2, False), (4, True), (8, True)])
+def test_slab_apply_with_neighbour_rows_as_halos_equals_the_single_domain_apply(storage, R, split):
+    L, nrhs, mask = 32, 3, 0b101
+    dtype, vt = STORAGE[storage]
+    g = D(random_gauge(L, 11))
+    cl, hp = qmg.DeviceArray(4 * L * L), qmg.DeviceArray(16 * L * L)
+    qmg.wilson_fill(cl, hp, g, L, L, 1.0)
+    cl_h, hp_h = cl.to_host(), hp.to_host()
+    n = 2 * L * L
+    x = cs.gaussian_cvec(n * nrhs, 5)
+    lhs0 = cs.gaussian_cvec(n * nrhs, 6)
+    Ll = L // R
+    nl = 2 * L * Ll
+    row = (L // 2) * 2                                # complex elements of one parity's row
+    shifts = (-0.07, 0.013, 0.021)
+    P = qmg
+    for pieces in (P.P_ALL | P.P_ZERO, P.P_ALL, P.P_EO | P.P_ZERO_E, P.P_OE | P.P_ZERO_O, P.P_EO | P.P_CLOVER_E | P.P_SHIFT_E,
+                   P.P_CLOVER_E | P.P_CLOVER_O | P.P_EO | P.P_OE | P.P_ZERO):
+        want = single_domain_apply(storage, L, cl_h, hp_h, x, pieces, lhs0, nrhs, mask, shifts)
+        xs = x.reshape(nrhs, 2, L, row)
+        for r in range(R):
+            y0 = r * Ll
+            dc, dh = to_storage(rows(cl_h, L, (L // 2) * 4, y0, Ll), storage), to_storage(rows(hp_h, L, (L // 2) * 4, y0, Ll), storage)
+            d = qmg.make_desc(L, Ll, 2, dc, dh, *shifts)
+            dx = D(np.concatenate([rows(x[k * n:(k + 1) * n], L, row, y0, Ll) for k in range(nrhs)]).astype(vt))
+            dl = D(np.concatenate([rows(lhs0[k * n:(k + 1) * n], L, row, y0, Ll) for k in range(nrhs)]).astype(vt))
+            lo = D(xs[:, :, (y0 - 1) % L].reshape(-1).astype(vt))            # [system][parity][hr][nc]
+            hi = D(xs[:, :, (y0 + Ll) % L].reshape(-1).astype(vt))
+            if split:   # interior first (it needs no halo), then the two boundary rows
+                qmg.stencil_apply_slab(dtype, d, dl, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=1)
+                qmg.stencil_apply_slab(dtype, d, dl, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=2)
+            else:
+                qmg.stencil_apply_slab(dtype, d, dl, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=0)
+            got = dl.to_host()
+            for k in range(nrhs):
+                assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], L, row, y0, Ll)), (storage, R, r, hex(pieces), k)
+
+
+@pytest.mark.parametrize("forced_rccl", [False, True])
+def test_library_exchange_on_one_rank_is_the_periodic_wrap(monkeypatch, forced_rccl):
+    """qmg_halo_exchange with one rank: device copies, or -- with a real one-rank communicator -- ncclSend / ncclRecv to self;
+    either way the slab IS the lattice and apply_slab must equal the periodic apply.  With the communicator up, the
+    distributed reductions run their all-reduce (of one rank: the value itself)."""
+    import ctypes as C
+    Lx, Ly, nrhs = 48, 16, 2
+    lib = qmg.lib()
+    if forced_rccl:
+        monkeypatch.setenv("QMG_COMM_FORCE_RCCL", "1")
+        uid = (C.c_char * 128)()
+        assert lib.qmg_comm_get_unique_id(uid) == 0 and lib.qmg_comm_init(uid, 1, 0) == 0
+        qmg.comm_set_distributed_reductions(True)
+    try:
+        rng = np.random.default_rng(2)
+        g = D(np.exp(1j * rng.uniform(-np.pi, np.pi, size=2 * Lx * Ly)))
+        cl, hp = qmg.DeviceArray(4 * Lx * Ly), qmg.DeviceArray(16 * Lx * Ly)
+        qmg.wilson_fill(cl, hp, g, Lx, Ly, 1.0)
+        d = qmg.make_desc(Lx, Ly, 2, cl, hp, 0.1)
+        n, row = 2 * Lx * Ly, Lx
+        x = cs.gaussian_cvec(n * nrhs, 8)
+        dx, want, got = D(x), qmg.DeviceArray(n * nrhs), qmg.DeviceArray(n * nrhs)
+        qmg.set_tuning("stencil_site", 7)
+        qmg.stencil_apply(d, want, dx, qmg.P_ALL | qmg.P_ZERO, nrhs, n)
+        qmg.set_tuning("stencil_site", 3)
+        lo, hi = qmg.DeviceArray(2 * row * nrhs), qmg.DeviceArray(2 * row * nrhs)
+        qmg.halo_exchange(qmg.C64, dx, Lx, Ly, 2, lo, hi, nrhs, n, 2 * row)
+        xs = x.reshape(nrhs, 2, Ly, row)
+        assert np.array_equal(lo.to_host(), xs[:, :, Ly - 1].reshape(-1)) and np.array_equal(hi.to_host(), xs[:, :, 0].reshape(-1))
+        qmg.stencil_apply_slab(qmg.C64, d, got, dx, lo, hi, qmg.P_ALL | qmg.P_ZERO, nrhs, n, 2 * row, 0b11)
+        assert np.array_equal(got.to_host(), want.to_host())
+        # reductions: one rank's sum over ranks is the local value, through the all-reduce when the communicator is real
+        assert qmg.norm2sq(dx, n) == pytest.approx(np.vdot(x[:n], x[:n]).real, rel=1e-13)
+        raw = qmg.batch_reduce(qmg.BRED_NORM2, dx, None, n, nrhs, n, 0b11)
+        assert raw[1].real == pytest.approx(np.vdot(x[n:], x[n:]).real, rel=1e-13)
+    finally:
+        if forced_rccl:
+            qmg.comm_set_distributed_reductions(False)
+            assert lib.qmg_comm_finalize() == 0
+
+
+def test_slab_entry_points_refuse_what_they_do_not_serve():
+    import ctypes as C
+    L = 16
+    cl, hp, v = qmg.DeviceArray(16 * L * L), qmg.DeviceArray(64 * L * L), qmg.DeviceArray(4 * L * L)
+    halo = qmg.DeviceArray(4 * L)
+    d4 = qmg.make_desc(L, L, 4, cl, hp)
+    lib = qmg.lib()
+    args = (C.c_void_p(v.ptr), C.c_void_p(v.ptr + 16 * 2 * L * L), C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), C.c_uint(0xFFF), 1, C.c_size_t(0), C.c_size_t(0),
+            C.c_uint(1), 0, None)
+    assert lib.qmg_stencil_apply_slab(qmg.C64, C.byref(d4), *args) == 3                      # nc = 4: unsupported this round
+    d2 = qmg.make_desc(L, L, 2, cl, hp)
+    assert lib.qmg_stencil_apply_slab(qmg.C64 | qmg.SLAB_H16, C.byref(d2), *args) == 1       # 16-bit matrices come with fp32 vectors
+    assert lib.qmg_stencil_apply_slab(7, C.byref(d2), *args) == 1
+    assert lib.qmg_halo_exchange(qmg.C64, C.c_void_p(v.ptr), L, 15, 2, C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), 1, C.c_size_t(0), C.c_size_t(0), None) == 1
