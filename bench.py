@@ -347,9 +347,36 @@ def f32_fine_apply(qmg, L, fixture, steps, warmup, barrier):
     out = {"workload": "Wilson apply_stencil_2D_M, %dx%d, nc=2, complex<float> matrices and vectors (qmg_stencil_apply_t QMG_C32)" % (L, L), "dtype": "f32 (complex64)",
            "gflops": vol * FLOP_PER_SITE * steps / wall / 1e9, "ms_per_step": wall / steps * 1e3, "parity_gate_rel_l2_vs_fp64_oracle": err,
            "roofline": {"bound": "hbm", "achieved": 192 * vol / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": 192 * vol / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_stencil_elem<float,2>",
+                        "frac": 192 * vol / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_stencil_site<1,1,true,false> (csrc/qmg_site.hip)",
                         "algorithmic_bytes_per_launch": 192 * vol, "avg_launch_ms": kern_ms, "note": "192 B/site (BASELINE.md); reported beside, never instead of, the fp64 line"}}
-    for a in (c32, h32, rhs, lhs):
+    # the same apply with the MATRICES stored in 16 bits (complex<half>; vectors complex<float>, fp32 arithmetic): 112 B/site.
+    # Not a reference configuration (SURVEY 8f-4 "16-bit-storage smoother"): it serves the smoother inside the fp32 K-cycle.
+    # Gate: against the fp64 oracle applied to the fp16-ROUNDED matrices, at fp32 accuracy.
+    c16, h16 = qmg.DeviceArray(4 * vol, np.float32), qmg.DeviceArray(16 * vol, np.float32)
+    qmg.convert_to_c16(c16, c32, qmg.C32, 4 * vol)
+    qmg.convert_to_c16(h16, h32, qmg.C32, 16 * vol)
+    d16 = qmg.make_desc(L, L, 2, c16, h16, MASS)
+
+    def rounded(a):
+        a = a.astype(np.complex64)
+        return (a.real.astype(np.float16).astype(np.float64) + 1j * a.imag.astype(np.float16).astype(np.float64))
+    want16 = tile_vector(ol.stencil_apply(ol.make_desc(64, 64, 2, rounded(clover), rounded(hopping), MASS), v), L, 2)
+
+    class W16:
+        def step(self_inner):
+            qmg.stencil_apply_h16(d16, lhs, rhs, qmg.P_ALL | qmg.P_ZERO)
+    w16 = W16()
+    w16.step()
+    err16 = float(np.linalg.norm(lhs.to_host().astype(np.complex128) - want16) / np.linalg.norm(want16))
+    if not err16 < 5e-6:
+        raise SystemExit("16-bit-matrix parity gate failed at L=%d: rel L2 error %.3e" % (L, err16))
+    wall16, kern16 = timed(qmg, w16, steps, warmup, barrier)
+    out["matrices_in_16_bit"] = {"ms_per_step": wall16 / steps * 1e3, "parity_gate_rel_l2_vs_fp64_oracle_on_rounded_matrices": err16,
+                                 "roofline": {"bound": "hbm", "achieved": 112 * vol / (kern16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": 112 * vol / (kern16 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                              "kernel": "k_stencil_site<0,1,true,false>", "algorithmic_bytes_per_launch": 112 * vol, "avg_launch_ms": kern16,
+                                              "note": "80 B/site of complex<half> matrices + 16 + 16 B/site of complex<float> vectors"}}
+    for a in (c32, h32, c16, h16, rhs, lhs):
         a.free()
     return out
 
@@ -368,6 +395,38 @@ def staggered_8rhs(qmg, L, fixture, steps, warmup, barrier, torch):
            "note": "whole step: apply (64/nrhs + 32 B/site/rhs) + norm2sq (16 B/site/rhs); the N-GPU form is `--workload staggered`"}
     wl.free()
     return out
+
+
+def slab_solve(L, world, rank):
+    """ONE Wilson system on ONE L x L lattice, strong-scaled over the ranks by y-slabs (drivers/slab_wilson_solve.cpp:
+    halo rows over RCCL send/recv overlapped with the interior apply, reductions summed over ranks, BiCGStab-6 of krylov.hpp
+    unchanged).  EVERY rank starts its child (the children build their own communicator: qmg_comm_init_env over
+    MASTER_ADDR : MASTER_PORT + 1); rank 0's child reports.  The same lattice, source and tolerance at every N, so
+    `solve_s` across the driver's N = 1, 2, 4, 8 runs is the strong-scaling curve and `x_norm2` must agree between them."""
+    import re
+    import subprocess
+    drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+    exe = os.path.join(drivers, "slab_wilson_solve")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    try:
+        p = subprocess.run([exe, str(L), "0.05", "6.0", "200", "1337", "1e-10", "1", "1"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
+                           capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "slab_wilson_solve timed out after 240 s on rank %d" % rank}
+    m = re.search(r"BiCGStab-6 (converged|FAILED) in (\d+) iterations, ([\d.e+-]+) s, (\d+) applies, true relative residual ([\d.e+-]+), \|b\| [\d.e+-]+, \|x\|\^2 ([\d.e+-]+), world (\d+)", p.stdout)
+    a = re.search(r"apply_M on a slab: ([\d.e+-]+) ms with the exchange overlapped, ([\d.e+-]+) ms serialised", p.stdout)
+    v = re.findall(r"slab apply vs single-domain apply, rel diff ([\d.e+-]+) \((ok|MISMATCH)\)", p.stdout)
+    if rank != 0:
+        return None
+    if not m or p.returncode != 0:
+        return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
+    return {"workload": "one Wilson solve (BiCGStab-6, tol 1e-10, mass 0.05, beta 6.0 device heatbath) on ONE %dx%d lattice cut into %d y-slab(s)" % (L, L, world),
+            "scaling": "strong", "world": int(m.group(7)), "converged": m.group(1) == "converged", "iterations": int(m.group(2)), "solve_s": float(m.group(3)),
+            "applies": int(m.group(4)), "true_rel_residual": float(m.group(5)), "x_norm2": float(m.group(6)),
+            "slab_apply_ms_exchange_overlapped": float(a.group(1)) if a else None, "slab_apply_ms_exchange_serialised": float(a.group(2)) if a else None,
+            "slab_apply_equals_single_domain_apply_on_rank0": bool(v) and v[0][1] == "ok",
+            "note": "each rank also builds the single-domain operator once and checks its slab apply (real exchange) against its rows of it"}
 
 
 def pmc_traffic(L):
@@ -629,6 +688,12 @@ def main():
         out["also_kcycle_f32_coarse_storage"] = kcycle_c3_f32_coarse()
         out["also_kcycle_batched"] = kcycle_c3_batched()
         out["also_kcycle_c5_shape"] = kcycle_c5_shape()
+
+    if not args.no_also:   # every rank takes part: the slabs of one lattice
+        barrier()
+        slab = slab_solve(L, world, rank)
+        if rank == 0:
+            out["also_slab_solve"] = slab
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fixture)

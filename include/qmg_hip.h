@@ -106,6 +106,7 @@ int qmg_stream_sync(void* stream);
 int qmg_event_create(void** ev);
 int qmg_event_destroy(void* ev);
 int qmg_event_record(void* ev, void* stream);
+int qmg_stream_wait_event(void* stream, void* ev);                     /* later work on `stream` waits for ev (no host sync) */
 int qmg_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
 
 /* ---------------- cshift (cshift/cshift_2d.h:45-236) ---------------- */

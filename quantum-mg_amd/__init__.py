@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qmg_init", "qmg_device_count", "qmg_status_string", "qmg_last_hip_error", "qmg_version",
     "qmg_malloc", "qmg_free", "qmg_mem_info", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
     "qmg_stream_create", "qmg_stream_destroy", "qmg_stream_sync",
-    "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms",
+    "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms", "qmg_stream_wait_event",
     "qmg_cshift", "qmg_stencil_apply", "qmg_stencil_apply_batch", "qmg_stencil_apply_mat32", "qmg_c64_to_c32", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",
     "qmg_build_dagger", "qmg_build_rbjacobi", "qmg_cmat_conjtrans",
     "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",

@@ -122,6 +122,12 @@ int qmg_event_record(void* ev, void* stream) {
   QMG_HIP_CHECK(hipEventRecord((hipEvent_t)ev, as_stream(stream)));
   return QMG_SUCCESS;
 }
+// make everything submitted to `stream` after this call wait for `ev` (cross-stream dependency without a host sync)
+int qmg_stream_wait_event(void* stream, void* ev) {
+  if (!ev) return QMG_ERR_INVALID;
+  QMG_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)ev, 0));
+  return QMG_SUCCESS;
+}
 int qmg_event_elapsed_ms(void* a, void* b, float* ms) {
   if (!a || !b || !ms) return QMG_ERR_INVALID;
   QMG_HIP_CHECK(hipEventSynchronize((hipEvent_t)b));

@@ -179,3 +179,32 @@ def test_slab_entry_points_refuse_what_they_do_not_serve():
     assert lib.qmg_stencil_apply_slab(qmg.C64 | qmg.SLAB_H16, C.byref(d2), *args) == 1       # 16-bit matrices come with fp32 vectors
     assert lib.qmg_stencil_apply_slab(7, C.byref(d2), *args) == 1
     assert lib.qmg_halo_exchange(qmg.C64, C.c_void_p(v.ptr), L, 15, 2, C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), 1, C.c_size_t(0), C.c_size_t(0), None) == 1
+
+
+@pytest.mark.parametrize("forced_rccl", [False, True])
+def test_slab_solve_driver_on_one_rank(forced_rccl):
+    """drivers/slab_wilson_solve.cpp: gauge generation, slab operator, the single-domain cross-check, the overlapped apply and a
+    BiCGStab-6 solve with the library's distributed reductions -- on one rank, without and with a real RCCL communicator (the
+    send / recv / all-reduce calls are then made for real, to self).  Both runs must tell the same story digit for digit."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if forced_rccl:
+        env["QMG_COMM_FORCE_RCCL"] = "1"
+    out = subprocess.run([os.path.join(drivers, "slab_wilson_solve"), "128", "0.05", "6.0", "100", "7"], cwd=drivers, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rel diff 0 (ok)" in out.stdout or re.search(r"rel diff [\d.]+e-1[4-9] \(ok\)", out.stdout)
+    m = re.search(r"BiCGStab-6 converged in (\d+) iterations, .* true relative residual ([\d.e+-]+), \|b\| ([\d.e+-]+), \|x\|\^2 ([\d.e+-]+), world 1", out.stdout)
+    assert m, out.stdout[-1500:]
+    assert float(m.group(2)) < 1e-9
+    # the same numbers with and without the communicator (kept across the two parametrisations)
+    key = (m.group(1), m.group(3), m.group(4))
+    seen = test_slab_solve_driver_on_one_rank.__dict__.setdefault("seen", key)
+    assert seen == key
+    # a world the rows do not divide into is refused by every rank together
+    bad = subprocess.run([os.path.join(drivers, "slab_wilson_solve"), "6", "0.05", "6.0", "1"], cwd=drivers, env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 0 or "do not split" in bad.stdout      # 6 rows on one rank are fine; the refusal needs world > 1 (not reachable on one GPU)
