@@ -15,6 +15,47 @@
 
 using namespace std;
 
+// Null-vector relaxation for `count` vectors of one level, `batch` at a time in lock step (the reference does
+// them one by one, tests/n13_wilson_kcycle/wilson_kcycle.cpp:340-366: guess -> orthogonalise against the finished vectors
+// -> BiCGStab-6 on A e = -A guess (tol 5e-5, 500 iterations) -> e + guess -> orthogonalise).  The solves of a batch share
+// every read of the operator; within a batch the guesses can only be orthogonalised against the batches before it, the
+// finished vectors are orthogonalised in the reference's order afterwards.  T = float runs the relaxation on complex<float>
+// copies of the operator and of the vectors (half the bytes of a bandwidth-bound loop that stops at 5e-5 anyway); the
+// vectors come back as complex<double> and everything downstream (chiral projection, block orthonormalisation, Galerkin
+// build) is fp64.
+template <typename T>
+inline bool relax_null_vectors_batched(Stencil2D* st, complex<double>** null_vectors, int count, long fsize, int batch, unsigned long long& seed) {
+  const bool f32 = sizeof(T) == sizeof(float);
+  if (f32 && !st->enable_f32_shadow()) { std::cout << "[QMG-ERROR]: no memory for the fp32 copy of the operator\n"; return false; }
+  BatchOp op(st, QMG_MATVEC_ORIGINAL);
+  for (int j0 = 0; j0 < count; j0 += batch) {
+    const int nb = (count - j0 < batch) ? count - j0 : batch;
+    const unsigned mask = qmg::full_mask(nb);
+    qmg::BatchPoolT<T> pool((size_t)fsize, nb);
+    qmg::BatchT<T> G = pool.get(), B = pool.get(), X = pool.get();
+    if (!G.p || !B.p || !X.p) { std::cout << "[QMG-ERROR]: no memory for a batch of " << nb << " null vectors\n"; return false; }
+    for (int k = 0; k < nb; k++) {
+      complex<double>* g = null_vectors[j0 + k];
+      gaussian(g, fsize, seed++);
+      for (int m = 0; m < j0; m++) orthogonal(g, null_vectors[m], fsize);
+      qmg::ok(qmg_convert(G.vec(k), qmg::dtype_of<T>::value, g, QMG_C64, (size_t)fsize, qmg::current_stream()), "qmg_convert");
+    }
+    apply_stencil_typed_batch<T>(B, G, mask, (void*)&op);
+    const qmg::cvec mone(nb, -1.0);
+    qmg::bblas<T>(QMG_BOP_CAX, &mone, 0, 0, 0, B, (size_t)fsize, mask);
+    qmg::bzero(X, (size_t)fsize, mask);
+    bminv_vector_bicgstab_l_zero_guess<T>(X, B, (int)fsize, 500, 5e-5, 6, apply_stencil_typed_batch<T>, (void*)&op, mask);
+    qmg::bcxpy(G, X, (size_t)fsize, mask);
+    for (int k = 0; k < nb; k++) {
+      complex<double>* v = null_vectors[j0 + k];
+      qmg::ok(qmg_convert(v, QMG_C64, X.vec(k), qmg::dtype_of<T>::value, (size_t)fsize, qmg::current_stream()), "qmg_convert");
+      for (int m = 0; m < j0 + k; m++) orthogonal(v, null_vectors[m], fsize);
+    }
+  }
+  if (f32) st->disable_f32_shadow();
+  return true;
+}
+
 struct N13 {
   int x_len, y_len, n_refine, coarse_dof;
   double mass, tol;
@@ -81,6 +122,12 @@ inline int N13::build(int argc, char** argv) {
   const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
   const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
   seed = 1337ull;
+  // null-vector relaxation: QMG_NULL_BATCH systems in lock step (default 8; 1 = one at a time in the reference's order, n13:340-366),
+  // on complex<float> copies of the level's operator unless QMG_NULL_F32=0 (the relaxation stops at 5e-5)
+  int null_batch = getenv("QMG_NULL_BATCH") ? atoi(getenv("QMG_NULL_BATCH")) : 8;
+  if (null_batch < 1) null_batch = 1;
+  if (null_batch > qmg::BATCH_MAX) null_batch = qmg::BATCH_MAX;
+  const bool null_f32 = getenv("QMG_NULL_F32") ? atoi(getenv("QMG_NULL_F32")) != 0 : true;
 
   verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
   verb.verb_prefix = "Level 0: ";
@@ -118,6 +165,11 @@ inline int N13::build(int argc, char** argv) {
     complex<double>** null_vectors = new complex<double>*[coarse_dof];
     for (int j = 0; j < coarse_dof; j++) { null_vectors[j] = allocate_vector<complex<double>>(fsize); zero_vector(null_vectors[j], fsize); }
     auto t0 = now();
+    if (null_batch > 1) {
+      bool done = null_f32 ? relax_null_vectors_batched<float>(mg_object->get_stencil(i - 1), null_vectors, coarse_dof / 2, fsize, null_batch, seed)
+                           : relax_null_vectors_batched<double>(mg_object->get_stencil(i - 1), null_vectors, coarse_dof / 2, fsize, null_batch, seed);
+      if (!done) return 5;
+    } else
     for (int j = 0; j < coarse_dof / 2; j++) {
       complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
       gaussian(rand_guess, fsize, seed++);

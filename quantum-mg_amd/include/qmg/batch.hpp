@@ -298,6 +298,132 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::BatchT<T>
 }
 
 // ---------------------------------------------------------------------------------------------
+// BiCGStab(L) for a batch: minv_vector_bicgstab_l of krylov.hpp per system, in lock step (the null-vector relaxation of
+// tests/n13_wilson_kcycle/wilson_kcycle.cpp:359, several null vectors at a time).  x0 = 0 is REQUIRED (the caller has
+// zeroed phi): r0 = b.  `iter` counts BiCG steps per system; a system that converges, breaks down or reaches max_iter is
+// frozen at the end of its L-block.  The closing updates of a block go through one multi-vector pass each.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+inline std::vector<inversion_info> bminv_vector_bicgstab_l_zero_guess(qmg::BatchT<T> phi, qmg::BatchT<T> phi0, int size, int max_iter, double eps, int L,
+                                                                      batch_matrix_op_t<T> matrix_vector, void* extra_info, unsigned mask) {
+  const int nrhs = phi.nrhs;
+  std::vector<inversion_info> inv(nrhs);
+  qmg::BatchPoolT<T> pool(phi.stride, nrhs);
+  std::vector<qmg::BatchT<T> > r(L + 1), u(L + 1);
+  for (int i = 0; i <= L; i++) { r[i] = pool.get(); u[i] = pool.get(); }
+  qmg::BatchT<T> rt = pool.get();
+  const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
+  qmg::bcopy(r[0], phi0, size, mask);
+  qmg::bcopy(rt, phi0, size, mask);
+  qmg::bzero(u[0], size, mask);
+  std::vector<double> rsq = bsq, bnorm(nrhs, 0.0);
+  std::vector<int> its(nrhs, 0), ops(nrhs, 0);
+  std::vector<bool> conv(nrhs, false);
+  qmg::cvec rho0(nrhs, 1.0), alpha(nrhs, 0.0), omega(nrhs, 1.0);
+  unsigned act = 0;
+  for (int k = 0; k < nrhs; k++) {
+    bnorm[k] = std::sqrt(bsq[k]);
+    if (!qmg::is_active(mask, k)) continue;
+    conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < eps * bnorm[k]);
+    if (!conv[k] && max_iter > 0) act |= 1u << k;
+  }
+  const qmg::cvec one(nrhs, 1.0);
+  std::vector<qmg::BatchT<T> > single(1);
+  auto bdot1 = [&](qmg::BatchT<T> a, qmg::BatchT<T> b, unsigned m) {   // <a_k, b_k> per system
+    single[0] = a;
+    const std::vector<qmg::cvec> d = qmg::bmultidot(single, 1, b, size, m);
+    qmg::cvec out(nrhs, 0.0);
+    for (int k = 0; k < nrhs; k++) out[k] = d[k][0];
+    return out;
+  };
+  std::vector<qmg::cvec> tau(nrhs, qmg::cvec((L + 1) * (L + 1), 0.0)), gamma(nrhs, qmg::cvec(L + 1, 0.0)), gammap(nrhs, qmg::cvec(L + 1, 0.0)),
+      gammapp(nrhs, qmg::cvec(L + 1, 0.0));
+  std::vector<std::vector<double> > sigma(nrhs, std::vector<double>(L + 1, 0.0));
+  while (act) {
+    for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k)) rho0[k] = -omega[k] * rho0[k];
+    for (int j = 0; j < L && act; j++) {   // BiCG part
+      const qmg::cvec rho1 = bdot1(rt, r[j], act);
+      qmg::cvec mbeta(nrhs, 0.0);
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        if (rho0[k] == 0.0) { act &= ~(1u << k); continue; }                 // breakdown: this system stops
+        mbeta[k] = -(alpha[k] * rho1[k] / rho0[k]);
+        rho0[k] = rho1[k];
+      }
+      if (!act) break;
+      for (int i = 0; i <= j; i++) qmg::bcaxpbyz(one, r[i], mbeta, u[i], u[i], size, act);   // u_i = r_i - beta u_i
+      matrix_vector(u[j + 1], u[j], act, extra_info);
+      const qmg::cvec gam = bdot1(rt, u[j + 1], act);
+      qmg::cvec malpha(nrhs, 0.0);
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        ops[k]++;
+        if (gam[k] == 0.0) { act &= ~(1u << k); continue; }
+        alpha[k] = rho0[k] / gam[k];
+        malpha[k] = -alpha[k];
+      }
+      if (!act) break;
+      for (int i = 0; i <= j; i++) qmg::bcaxpy(malpha, u[i + 1], r[i], size, act);
+      matrix_vector(r[j + 1], r[j], act, extra_info);
+      qmg::bcaxpy(alpha, u[0], phi, size, act);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k)) { ops[k]++; its[k]++; }
+    }
+    if (!act) break;
+    for (int j = 1; j <= L && act; j++) {   // MR part: modified Gram-Schmidt on r_1..r_L
+      for (int i = 1; i < j; i++) {
+        const qmg::cvec d = bdot1(r[i], r[j], act);
+        qmg::cvec mt(nrhs, 0.0);
+        for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k)) { tau[k][i * (L + 1) + j] = d[k] / sigma[k][i]; mt[k] = -tau[k][i * (L + 1) + j]; }
+        qmg::bcaxpy(mt, r[i], r[j], size, act);
+      }
+      std::vector<qmg::BatchT<T> > two(2);
+      two[0] = r[j]; two[1] = r[0];
+      // <r_j, r_j> and <r_j, r_0> in one pass over r_j: d[k][0] = <r_j, r_j>, d[k][1] = <r_0, r_j> = conj <r_j, r_0>
+      const std::vector<qmg::cvec> d = qmg::bmultidot(two, 2, r[j], size, act);
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        sigma[k][j] = d[k][0].real();
+        if (sigma[k][j] == 0.0) { act &= ~(1u << k); continue; }
+        gammap[k][j] = std::conj(d[k][1]) / sigma[k][j];
+      }
+    }
+    if (!act) break;
+    std::vector<qmg::cvec> cx(nrhs, qmg::cvec(L, 0.0)), cr(nrhs, qmg::cvec(L, 0.0)), cu(nrhs, qmg::cvec(L, 0.0));
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(act, k)) continue;
+      qmg::cvec &g = gamma[k], &gp = gammap[k], &gpp = gammapp[k], &t = tau[k];
+      g[L] = gp[L];
+      omega[k] = g[L];
+      for (int j = L - 1; j >= 1; j--) {
+        g[j] = gp[j];
+        for (int i = j + 1; i <= L; i++) g[j] -= t[j * (L + 1) + i] * g[i];
+      }
+      for (int j = 1; j < L; j++) {
+        gpp[j] = g[j + 1];
+        for (int i = j + 1; i < L; i++) gpp[j] += t[j * (L + 1) + i] * g[i + 1];
+      }
+      // x += gamma_1 r_0 + sum_{j<L} gamma''_j r_j ; r_0 -= sum_{j<=L} gamma'_j r_j ; u_0 -= sum_{j<=L} gamma_j u_j
+      cx[k][0] = g[1];
+      for (int j = 1; j < L; j++) cx[k][j] = gpp[j];
+      for (int j = 1; j <= L; j++) { cr[k][j - 1] = -gp[j]; cu[k][j - 1] = -g[j]; }
+    }
+    std::vector<qmg::BatchT<T> > r0L(r.begin(), r.begin() + L), r1L(r.begin() + 1, r.end()), u1L(u.begin() + 1, u.end());
+    qmg::bmulti_caxpy(cx, r0L, L, phi, size, act);     // reads r_0 before it changes
+    qmg::bmulti_caxpy(cr, r1L, L, r[0], size, act);
+    qmg::bmulti_caxpy(cu, u1L, L, u[0], size, act);
+    const std::vector<double> t2 = qmg::bnorm2sq(r[0], size, act);
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(act, k)) continue;
+      rsq[k] = t2[k];
+      if (std::sqrt(rsq[k]) < eps * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
+      else if (its[k] >= max_iter) act &= ~(1u << k);
+    }
+  }
+  for (int k = 0; k < nrhs; k++) { inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = "BiCGStab-L (batch)"; }
+  return inv;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flexible GCR with restarts for a batch: qmg_gcr_core of krylov.hpp per system, in lock step.  All systems start
 // together, so the basis index kb (and with it the restart points) is common; everything else is per system.
 // zero_guess: the caller has zeroed phi, r0 = b (krylov.hpp ZeroGuess).
