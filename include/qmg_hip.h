@@ -318,6 +318,17 @@ int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, 
                          void* stream);
 int qmg_comm_set_distributed_reductions(int on);
 
+/* ---------------- the Wilson operator straight from the gauge links (csrc/qmg_wilson.hip, kernel W) ----------------
+ * Same result as qmg_wilson_fill + qmg_stencil_apply (operators/wilson.h:153-209 + stencil_2d.h:912-936), without the stored
+ * matrices: 96 B/site instead of 384 in fp64 (48 instead of 192 in fp32).  d: the vectors' lattice (nc = 2) and the shifts;
+ * gauge: links in `dtype` on the lattice Lx x gauge_Ly, the vectors covering its rows y0 .. y0 + d->Ly - 1.  Whole lattice:
+ * gauge_Ly = d->Ly, y0 = 0, halos NULL, rows 0.  y-slab: halos from qmg_halo_exchange, rows as in qmg_stencil_apply_slab.
+ * Piece sets served: clover + every hop of the processed parities (shift pieces optional), or every hop alone;
+ * QMG_ERR_UNSUPPORTED otherwise -- the stored stencil serves the rest. */
+int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
+                            const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows,
+                            void* stream);
+
 /* ---------------- tuning hooks (not part of the reference surface) ---------------- */
 /* Dispatch / codegen knobs, all with the defaults the measurements in profiles/ chose; results never depend on them
  * beyond summation order.  Unknown keys return QMG_ERR_INVALID.

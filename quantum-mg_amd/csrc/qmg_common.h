@@ -153,6 +153,18 @@ __device__ __forceinline__ void ldc_pack(const void* base, long ipack, cplx (&v)
   }
 }
 template <typename T, int W>
+__device__ __forceinline__ void ldc_pack_nt(const void* base, long ipack, cplx (&v)[W]) {   // read-once streams
+  if (sizeof(T) == 4 && W == 2) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 r = __builtin_nontemporal_load(reinterpret_cast<const f4*>(base) + ipack);
+    v[0] = make_double2((double)r.x, (double)r.y);
+    v[W - 1] = make_double2((double)r.z, (double)r.w);
+  } else {
+#pragma unroll
+    for (int w = 0; w < W; w++) v[w] = ldc_nt<T>(base, ipack * W + w);
+  }
+}
+template <typename T, int W>
 __device__ __forceinline__ void stc_pack(void* base, long ipack, const cplx (&v)[W]) {
   if (sizeof(T) == 4 && W == 2) {
     reinterpret_cast<float4*>(base)[ipack] = make_float4((float)v[0].x, (float)v[0].y, (float)v[W - 1].x, (float)v[W - 1].y);
@@ -178,6 +190,7 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
 }
 
 extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
+extern int g_xfer_pack;   // qmg_transfer.hip; "xfer_pack"
 extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
 extern int g_site_block, g_site_gy, g_site_generic;   // qmg_site.hip; "site_block", "site_gy", "site_generic"
 

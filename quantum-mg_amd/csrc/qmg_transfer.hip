@@ -30,33 +30,46 @@ __device__ __forceinline__ long coarse_site_index(const XferGeom& g, int cx, int
 
 // ---------------- prolong: fine[k] += sum_d null[d][k] * coarse[ci(k)*cnc + d] ----------------
 // T = storage scalar of the null vectors and of both vectors; arithmetic in fp64 registers.
-template <typename T>
+// W = elements per lane: 1, or 2 for complex<float> with an even fnc -- then every access is one 16-byte load / store as in
+// fp64 (with 8-byte accesses the same number of instructions moves half the bytes: the fp32 prolong ran at 0.69 of peak).
+template <typename T, int W>
 __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse,
                                                    void* __restrict__ fine, const XferGeom g) {
-  const long row_elems = (long)g.fhr * g.fnc;
+  const long row_packs = (long)g.fhr * g.fnc / W;
   const int nrows = 2 * g.fLy;
   for (int row = blockIdx.y; row < nrows; row += gridDim.y) {
     const int p = row / g.fLy, y = row - p * g.fLy;
     const int s = (y + p) & 1;
     const int cy = y / g.by;
-    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < row_elems; t += (long)gridDim.x * BLOCK) {
-      const int j = (int)(t / g.fnc);
+    for (long t = (long)blockIdx.x * BLOCK + threadIdx.x; t < row_packs; t += (long)gridDim.x * BLOCK) {
+      const int j = (int)(t * W / g.fnc);                       // the W elements of a pack belong to one site (fnc even)
       const int cx = (2 * j + s) / g.bx;
       const long ci = coarse_site_index(g, cx, cy);
-      const long k = ((long)p * g.fhalf_vol + (long)y * g.fhr) * g.fnc + t;
+      const long kp = ((long)p * g.fhalf_vol + (long)y * g.fhr) * g.fnc / W + t;   // pack index in the fine vector
       const long cv = ci * g.cnc;
-      cplx acc = ldc<T>(fine, k);
+      cplx acc[W];
+      ldc_pack<T, W>(fine, kp, acc);
       // the null vectors are read exactly once: non-temporal, 8 loads in flight per lane before the FMAs
       int d = 0;
       for (; d + 8 <= nvec; d += 8) {
-        cplx v[8];
+        cplx v[8][W];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = ldc_nt<T>(nullv, (long)(d + q) * g.fsize + k);
+        for (int q = 0; q < 8; q++) ldc_pack_nt<T, W>(nullv, (long)(d + q) * (g.fsize / W) + kp, v[q]);
 #pragma unroll
-        for (int q = 0; q < 8; q++) cmac(acc, v[q], ldc<T>(coarse, cv + d + q));
+        for (int q = 0; q < 8; q++) {
+          const cplx c = ldc<T>(coarse, cv + d + q);
+#pragma unroll
+          for (int w = 0; w < W; w++) cmac(acc[w], v[q][w], c);
+        }
       }
-      for (; d < nvec; d++) cmac(acc, ldc<T>(nullv, (long)d * g.fsize + k), ldc<T>(coarse, cv + d));
-      stc<T>(fine, k, acc);
+      for (; d < nvec; d++) {
+        cplx v[W];
+        ldc_pack<T, W>(nullv, (long)d * (g.fsize / W) + kp, v);
+        const cplx c = ldc<T>(coarse, cv + d);
+#pragma unroll
+        for (int w = 0; w < W; w++) cmac(acc[w], v[w], c);
+      }
+      stc_pack<T, W>(fine, kp, acc);
     }
   }
 }
@@ -67,12 +80,12 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ null
 // null vectors at a time in registers; LDS sums the TPG partials.  One writer per (site, d): no atomics.
 constexpr int XFER_DC = 8;
 
-template <typename T>
+template <typename T, int W>
 __global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine,
                                                     void* __restrict__ coarse, const XferGeom g, int NG, int TPG) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* red = reinterpret_cast<cplx*>(smem_raw);   // [BLOCK][XFER_DC]
-  const int G = (g.bx / 2) * g.fnc;
+  const int G = (g.bx / 2) * g.fnc / W;          // packs of W elements (16 bytes) a coarse site owns on a fine half-row
   const int grp = threadIdx.x / TPG;
   const int l = threadIdx.x - grp * TPG;
   const int cLx = 2 * g.chr;
@@ -88,13 +101,19 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nul
         for (int rr = 0; rr < 2 * g.by; rr++) {
           const int p = rr / g.by;
           const int y = cy * g.by + (rr - p * g.by);
-          const long base = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc;
+          const long base = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc / W;
           for (int el = l; el < G; el += TPG) {
-            const long k = base + el;
-            const cplx f = ldc<T>(fine, k);
+            const long kp = base + el;
+            cplx f[W];
+            ldc_pack<T, W>(fine, kp, f);
 #pragma unroll
             for (int q = 0; q < XFER_DC; q++)
-              if (q < dn) cmac_conj(acc[q], ldc_nt<T>(nullv, (long)(d0 + q) * g.fsize + k), f);   // read-once stream: non-temporal
+              if (q < dn) {
+                cplx v[W];
+                ldc_pack_nt<T, W>(nullv, (long)(d0 + q) * (g.fsize / W) + kp, v);   // read-once stream: non-temporal
+#pragma unroll
+                for (int w = 0; w < W; w++) cmac_conj(acc[q], v[w], f[w]);
+              }
           }
         }
       }
@@ -466,17 +485,25 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_small(const void* __restric
   }
 }
 
+// two complex<float> per lane (16-byte accesses): even fnc (a pack stays inside one site), 16-byte aligned arrays
+template <typename T>
+static bool xfer_pack2(const XferGeom& g, const void* nullvecs, const void* fine) {
+  return sizeof(T) == sizeof(float) && g_xfer_pack && !(g.fnc & 1) && !(g.fsize & 1) && aligned16(nullvecs) && aligned16(fine);
+}
+
 template <typename T>
 static int launch_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse, const XferGeom& g, hipStream_t st) {
   if ((g.bx & 1) == 0) {
-    const int G = (g.bx / 2) * g.fnc;
+    const bool pack2 = xfer_pack2<T>(g, nullvecs, fine);
+    const int G = (g.bx / 2) * g.fnc / (pack2 ? 2 : 1);
     int NG = BLOCK / G;
     if (NG < 1) NG = 1;
     const int cLx = 2 * g.chr;
     if (NG > cLx) NG = cLx;
     const int TPG = BLOCK / NG;
     dim3 grid((unsigned)((cLx + NG - 1) / NG), g.cLy > 65535 ? 65535 : g.cLy);
-    k_restrict<T><<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>(nullvecs, nvec, fine, coarse, g, NG, TPG);
+    if (pack2) k_restrict<T, 2><<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>(nullvecs, nvec, fine, coarse, g, NG, TPG);
+    else k_restrict<T, 1><<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>(nullvecs, nvec, fine, coarse, g, NG, TPG);
   } else {
     k_restrict_generic<T><<<grid_1d((size_t)4 * g.chalf_vol * nvec / 2), BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g);
   }
@@ -486,16 +513,19 @@ static int launch_restrict(const void* nullvecs, int nvec, const void* fine, voi
 
 template <typename T>
 static int launch_prolong(const void* nullvecs, int nvec, const void* coarse, void* fine, const XferGeom& g, hipStream_t st) {
-  const long row_elems = (long)g.fhr * g.fnc;
-  unsigned gx = (unsigned)((row_elems + BLOCK - 1) / BLOCK);
+  const bool pack2 = xfer_pack2<T>(g, nullvecs, fine);
+  const long row_packs = (long)g.fhr * g.fnc / (pack2 ? 2 : 1);
+  unsigned gx = (unsigned)((row_packs + BLOCK - 1) / BLOCK);
   if (gx > 1024) gx = 1024;
   const int nrows = 2 * g.fLy;
   dim3 grid(gx, nrows > 65535 ? 65535 : nrows);
-  k_prolong<T><<<grid, BLOCK, 0, st>>>(nullvecs, nvec, coarse, fine, g);
+  if (pack2) k_prolong<T, 2><<<grid, BLOCK, 0, st>>>(nullvecs, nvec, coarse, fine, g);
+  else k_prolong<T, 1><<<grid, BLOCK, 0, st>>>(nullvecs, nvec, coarse, fine, g);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
 
+int g_xfer_pack = 1;   // tuning knob "xfer_pack": complex<float> transfer kernels move two elements per lane (16-byte accesses)
 int g_xfer_tile = 1;   // tuning knob "xfer_tile": 1 = batched transfer as LDS-tiled kernels, 0 = system by system
 
 // sites per prolong tile: a fine half-row segment of at least 512 bytes where the lattice allows, LDS <= 48 KB

@@ -1,0 +1,281 @@
+// qmg_wilson.hip -- the Wilson operator applied STRAIGHT FROM THE GAUGE LINKS (kernel W): no stored stencil matrices.
+//
+// The reference's Wilson2D fills a general 2x2-matrix stencil from the U(1) links (operators/wilson.h:153-209) and applies it
+// with the general stencil code: 5 matrices of 64 B + 2 vectors of 32 B = 384 B/site in fp64.  Every one of those matrices
+// is a fixed 2x2 spin pattern times ONE link, so they can be rebuilt in registers from the four links a site touches:
+//   +x: 1/2 [[-w, 1],[ 1,-w]] Ux(x)        -x: 1/2 [[-w,-1],[-1,-w]] conj Ux(x - x^)
+//   +y: 1/2 [[-w,-i],[ i,-w]] Uy(x)        -y: 1/2 [[-w, i],[-i,-w]] conj Uy(x - y^)        clover: 2w on the diagonal
+// Bytes: every link is used by the two sites it joins, so the links cost 2 x 16 B/site (the second use is an L2 hit, like
+// the neighbours of the right-hand side) -- 32 + 32 + 32 = 96 B/site in fp64 (1/4 of the stored stencil), 48 B/site in fp32.
+// The arithmetic is the stored path's: the matrix entries are formed by the same single multiplications k_wilson_fill does
+// and enter the same FMA sequence as the site kernel (qmg_site.hip: per-column partial sums, added at the end), so in fp64
+// the result is BIT-IDENTICAL to qmg_stencil_apply on the filled stencil through that kernel (tests/test_gpu_wilson_direct.py).
+//
+// Layout: fp64 -- two lanes per site, lane c holds component c of every site vector it needs (one 16-byte chunk each,
+// perfectly coalesced), accumulates column c's contribution to both output rows and swaps one complex number with its
+// partner (DPP); fp32 -- one lane per site (the site vector is one 16-byte chunk).  Links: own Ux, Uy and the -x / -y
+// neighbours' (opposite parity).  Load phase as raw registers behind a scheduling barrier, as in qmg_site.hip.
+// Piece sets served: clover + all hops (+ shifts) of the processed parities (apply_M and its one-parity forms) and hops
+// only (D_eo / D_oe); anything else returns QMG_ERR_UNSUPPORTED and the caller uses the stored stencil.
+// y-slabs: the links are indexed on the GLOBAL lattice (replicated, 32 B/site), only the right-hand side's rows
+// -1 / Ly come from halo buffers.
+#include "qmg_common.h"
+
+namespace qmg {
+
+struct WilsonArgs {
+  const void* gauge;       // [mu][global site] complex<T>
+  void* lhs;
+  const void* rhs;
+  int hr, Ly;              // the vectors' lattice (a slab: its local rows)
+  int gLy, gy0;            // the gauge field's lattice and the slab's first row on it
+  long half_vol, ghalf_vol;
+  unsigned pieces;
+  int nrhs;
+  long vec_stride;
+  int par_first, par_count, nrows;
+  double w;
+  double shift[2], eo_shift[2], dof_shift[2];
+  int ridx[16];
+  const void* halo_lo;
+  const void* halo_hi;
+  long halo_stride;
+  int y_first, y_count, boundary_only;
+};
+
+typedef float w4f __attribute__((ext_vector_type(4)));
+typedef float w2f __attribute__((ext_vector_type(2)));
+typedef double w2d __attribute__((ext_vector_type(2)));
+
+template <typename R>
+__device__ __forceinline__ void fmac2w(R& ax, R& ay, R mx, R my, R bx, R by) {
+  ax = fma(mx, bx, ax); ax = fma(-my, by, ax);
+  ay = fma(mx, by, ay); ay = fma(my, bx, ay);
+}
+
+// the four hop matrices' entries [row][col] for column c from the links (k_wilson_fill's multiplications, qmg_fill.hip)
+template <typename R>
+struct HopCol { R m0x, m0y, m1x, m1y; };   // entry (row 0, col c) and (row 1, col c)
+template <typename R>
+__device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw) {
+  // (ux, uy) = the link (already conjugated for the backward directions)
+  const R dx = hw * ux, dy = hw * uy;                 // diagonal entry: -w/2 U
+  const R h = (R)0.5;
+  R ox, oy;                                           // off-diagonal entry (row != col)
+  HopCol<R> o;
+  if (d == 0) { ox = h * ux; oy = h * uy; }                                   // +x: U/2 both
+  else if (d == 2) { ox = -h * ux; oy = -h * uy; }                            // -x: -U/2 both
+  else if (d == 1) {                                                          // +y: [0][1] = -iU/2, [1][0] = iU/2
+    if (c == 1) { ox = h * uy; oy = -h * ux; } else { ox = -h * uy; oy = h * ux; }
+  } else {                                                                    // -y: [0][1] = iU/2, [1][0] = -iU/2
+    if (c == 1) { ox = -h * uy; oy = h * ux; } else { ox = h * uy; oy = -h * ux; }
+  }
+  if (c == 0) { o.m0x = dx; o.m0y = dy; o.m1x = ox; o.m1y = oy; }
+  else { o.m0x = ox; o.m0y = oy; o.m1x = dx; o.m1y = dy; }
+  return o;
+}
+
+// T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only.
+template <typename T, int SHAPE, bool ZERO, bool BATCH>
+__global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
+  constexpr bool F64 = sizeof(T) == 8;
+  constexpr int LPS = F64 ? 2 : 1;
+  constexpr int NCOL = F64 ? 1 : 2;                // columns a lane handles
+  typedef T R;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
+  if (j >= a.hr) return;
+  const long sys_bytes = a.vec_stride * (long)(2 * sizeof(T));
+  const R hw = (R)(-0.5 * a.w), cw = (R)(2.0 * a.w);
+  for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
+    const int yi = (a.par_count == 2) ? (row >> 1) : row;
+    const int y = a.boundary_only ? (yi ? a.Ly - 1 : 0) : a.y_first + yi;
+    const bool do_shift = (a.pieces >> (10 + p)) & 1u;
+    const bool do_zero = ZERO || ((a.pieces >> (12 + p)) & 1u);
+    const long site = (long)p * a.half_vol + (long)y * a.hr + j;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const int s = (y + p) & 1;
+    int jp = j + s;     if (jp == a.hr) jp = 0;
+    int jm = j + s - 1; if (jm < 0) jm = a.hr - 1;
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
+    const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+    const long nb[4] = {opp + (long)y * a.hr + jp, opp + (long)yp * a.hr + j, opp + (long)y * a.hr + jm, opp + (long)ym * a.hr + j};
+    // links on the global lattice
+    const int gy = a.gy0 + y;
+    const int gym = (gy == 0) ? a.gLy - 1 : gy - 1;
+    const long gvol = 2 * a.ghalf_vol;
+    const long gsite = (long)p * a.ghalf_vol + (long)gy * a.hr + j;
+    const long gxm = (long)(1 - p) * a.ghalf_vol + (long)gy * a.hr + jm;
+    const long gymi = (long)(1 - p) * a.ghalf_vol + (long)gym * a.hr + j;
+    const T* g = reinterpret_cast<const T*>(a.gauge);
+    // ---- load phase: first system's chunks, then the four links (raw)
+    const bool from_hi = a.halo_hi && y + 1 == a.Ly, from_lo = a.halo_lo && y == 0;
+    const long hsite = (long)(1 - p) * a.hr + j;
+    w4f xr[5];                                     // neighbours +x +y -x -y, own
+    auto load_x = [&](int k) {
+      const long off = (long)a.ridx[k] * sys_bytes;
+      const char* x = reinterpret_cast<const char*>(a.rhs) + off;
+      const long hoff = (long)a.ridx[k] * a.halo_stride * (long)(2 * sizeof(T));
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const char* base = x;
+        long idx = nb[d];
+        if (d == 1 && from_hi) { base = reinterpret_cast<const char*>(a.halo_hi) + hoff; idx = hsite; }
+        if (d == 3 && from_lo) { base = reinterpret_cast<const char*>(a.halo_lo) + hoff; idx = hsite; }
+        xr[d] = *(reinterpret_cast<const w4f*>(base) + idx * LPS + c0);
+      }
+      if (SHAPE == 1 || do_shift) xr[4] = *(reinterpret_cast<const w4f*>(x) + site * LPS + c0);
+    };
+    load_x(0);
+    R lx[4], ly[4];                                // links per direction, conjugated for the backward ones
+    if (F64) {
+      const w2d u0 = __builtin_nontemporal_load(reinterpret_cast<const w2d*>(g) + gsite);
+      const w2d u1 = __builtin_nontemporal_load(reinterpret_cast<const w2d*>(g) + gvol + gsite);
+      const w2d u2 = *(reinterpret_cast<const w2d*>(g) + gxm);
+      const w2d u3 = *(reinterpret_cast<const w2d*>(g) + gvol + gymi);
+      __builtin_amdgcn_sched_barrier(0);
+      lx[0] = (R)u0.x; ly[0] = (R)u0.y; lx[1] = (R)u1.x; ly[1] = (R)u1.y;
+      lx[2] = (R)u2.x; ly[2] = -(R)u2.y; lx[3] = (R)u3.x; ly[3] = -(R)u3.y;
+    } else {
+      const w2f u0 = __builtin_nontemporal_load(reinterpret_cast<const w2f*>(g) + gsite);
+      const w2f u1 = __builtin_nontemporal_load(reinterpret_cast<const w2f*>(g) + gvol + gsite);
+      const w2f u2 = *(reinterpret_cast<const w2f*>(g) + gxm);
+      const w2f u3 = *(reinterpret_cast<const w2f*>(g) + gvol + gymi);
+      __builtin_amdgcn_sched_barrier(0);
+      lx[0] = (R)u0.x; ly[0] = (R)u0.y; lx[1] = (R)u1.x; ly[1] = (R)u1.y;
+      lx[2] = (R)u2.x; ly[2] = -(R)u2.y; lx[3] = (R)u3.x; ly[3] = -(R)u3.y;
+    }
+    const int nsys = BATCH ? a.nrhs : 1;
+    for (int k = 0; k < nsys; k++) {
+      if (BATCH && k > 0) { load_x(k); __builtin_amdgcn_sched_barrier(0); }
+      char* out = reinterpret_cast<char*>(a.lhs) + (long)a.ridx[k] * sys_bytes;
+      // acc[col][row]: column `col`'s contribution to output row `row` (the site kernel's per-lane partial sums)
+      R ax[NCOL][2], ay[NCOL][2];
+#pragma unroll
+      for (int cc = 0; cc < NCOL; cc++) { ax[cc][0] = ax[cc][1] = ay[cc][0] = ay[cc][1] = (R)0; }
+#pragma unroll
+      for (int cc = 0; cc < NCOL; cc++) {
+        const int c = F64 ? c0 : cc;
+        // component c of a chunk: fp64 chunk = that component; fp32 chunk = (x0.re, x0.im, x1.re, x1.im)
+        auto comp = [&](const w4f& v, R& vx, R& vy) {
+          if (F64) { const w2d q = __builtin_bit_cast(w2d, v); vx = (R)q.x; vy = (R)q.y; }
+          else { vx = (R)(c ? v.z : v.x); vy = (R)(c ? v.w : v.y); }
+        };
+        R vx, vy;
+        if (SHAPE == 1) {   // clover first: 2w on the diagonal (row == col)
+          comp(xr[4], vx, vy);
+          fmac2w<R>(ax[cc][c], ay[cc][c], cw, (R)0, vx, vy);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          comp(xr[d], vx, vy);
+          const HopCol<R> m = hop_col<R>(d, c, lx[d], ly[d], hw);
+          fmac2w<R>(ax[cc][0], ay[cc][0], m.m0x, m.m0y, vx, vy);
+          fmac2w<R>(ax[cc][1], ay[cc][1], m.m1x, m.m1y, vx, vy);
+        }
+        if (do_shift) {   // shift +- eo_shift +- dof_shift on the diagonal (stencil_2d.h:890-908)
+          const double sg = p ? -1.0 : 1.0, dg = c ? -1.0 : 1.0;
+          const R sx = (R)(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0]), sy = (R)(a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+          comp(xr[4], vx, vy);
+          fmac2w<R>(ax[cc][c], ay[cc][c], sx, sy, vx, vy);
+        }
+      }
+      if (F64) {
+        // lane c keeps row c: own column's part + the partner's part of that row
+        const int c = c0;
+        const double sendx = c ? (double)ax[0][0] : (double)ax[0][1], sendy = c ? (double)ay[0][0] : (double)ay[0][1];
+        const double recvx = lane_xor1(sendx), recvy = lane_xor1(sendy);
+        const double ownx = c ? (double)ax[0][1] : (double)ax[0][0], owny = c ? (double)ay[0][1] : (double)ay[0][0];
+        // row r = col0 part + col1 part, in that order (the site kernel adds lane c=0's value and lane c=1's)
+        w2d o;
+        o.x = c ? (recvx + ownx) : (ownx + recvx);
+        o.y = c ? (recvy + owny) : (owny + recvy);
+        w2d* dst = reinterpret_cast<w2d*>(out) + site * 2 + c;
+        if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
+        __builtin_nontemporal_store(o, dst);
+      } else {
+        w4f o;
+        o.x = (float)(ax[0][0] + ax[NCOL - 1][0]); o.y = (float)(ay[0][0] + ay[NCOL - 1][0]);
+        o.z = (float)(ax[0][1] + ax[NCOL - 1][1]); o.w = (float)(ay[0][1] + ay[NCOL - 1][1]);
+        w4f* dst = reinterpret_cast<w4f*>(out) + site;
+        if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
+        __builtin_nontemporal_store(o, dst);
+      }
+    }
+  }
+}
+
+template <typename T, bool BATCH>
+static void launch_wilson_b(const WilsonArgs& a, int shape, bool zero, dim3 grid, hipStream_t st) {
+  if (shape == 1) { if (zero) k_wilson_direct<T, 1, true, BATCH><<<grid, BLOCK, 0, st>>>(a); else k_wilson_direct<T, 1, false, BATCH><<<grid, BLOCK, 0, st>>>(a); }
+  else { if (zero) k_wilson_direct<T, 2, true, BATCH><<<grid, BLOCK, 0, st>>>(a); else k_wilson_direct<T, 2, false, BATCH><<<grid, BLOCK, 0, st>>>(a); }
+}
+
+}  // namespace qmg
+
+using namespace qmg;
+
+extern "C" {
+
+// lhs (+)= pieces(M_Wilson) rhs from the gauge links; d carries the vectors' lattice (Lx, Ly; nc must be 2) and the shifts,
+// its clover / hopping pointers are ignored.  gauge: [2][Lx * gauge_Ly] links in `dtype` on the lattice Lx x gauge_Ly, of
+// which the vectors cover rows y0 .. y0 + d->Ly - 1 (the whole lattice: gauge_Ly = d->Ly, y0 = 0).  halo_lo / halo_hi:
+// NULL (periodic in y) or the y-slab halos of qmg_halo_exchange; rows as in qmg_stencil_apply_slab.
+// Serves: clover + every hop of the processed parities (with or without the shift pieces) and hops only; other piece sets
+// return QMG_ERR_UNSUPPORTED (use the stored stencil).  lhs must not alias rhs unless only one parity is written from the other.
+int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
+                            const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows,
+                            void* stream) {
+  if (!valid_dtype(dtype) || !d || !gauge || !lhs || !rhs || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2) return QMG_ERR_INVALID;
+  if (!valid_lattice(d->Lx, d->Ly) || !valid_lattice(d->Lx, gauge_Ly) || y0 < 0 || (y0 & 1) || y0 + d->Ly > gauge_Ly) return QMG_ERR_INVALID;
+  if (d->nc != 2) return QMG_ERR_UNSUPPORTED;
+  if ((halo_lo == nullptr) != (halo_hi == nullptr)) return QMG_ERR_INVALID;
+  if (!halo_lo && (gauge_Ly != d->Ly || rows != 0)) return QMG_ERR_INVALID;   // a slab needs its halos
+  if (nrhs > 1 && (vec_stride < (size_t)d->Lx * d->Ly * 2 || (halo_lo && halo_stride < (size_t)d->Lx * 2))) return QMG_ERR_INVALID;
+  WilsonArgs a;
+  a.gauge = gauge; a.lhs = lhs; a.rhs = rhs;
+  a.hr = d->Lx / 2; a.Ly = d->Ly; a.gLy = gauge_Ly; a.gy0 = y0;
+  a.half_vol = (long)a.hr * d->Ly; a.ghalf_vol = (long)a.hr * gauge_Ly;
+  a.pieces = pieces; a.vec_stride = (long)vec_stride; a.w = wilson_coeff;
+  a.nrhs = 0;
+  for (int k = 0; k < 16; k++) a.ridx[k] = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) a.ridx[a.nrhs++] = k;
+  if (a.nrhs == 0) return QMG_SUCCESS;
+  for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
+  const unsigned even_bits = QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E;
+  const unsigned odd_bits = QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O;
+  const bool ev = pieces & even_bits, od = pieces & odd_bits;
+  if (!ev && !od) return QMG_SUCCESS;
+  a.par_first = ev ? 0 : 1;
+  a.par_count = (ev && od) ? 2 : 1;
+  a.halo_lo = halo_lo; a.halo_hi = halo_hi; a.halo_stride = (long)halo_stride;
+  a.boundary_only = rows == 2;
+  a.y_first = rows == 1 ? 1 : 0;
+  a.y_count = rows == 2 ? 2 : rows == 1 ? d->Ly - 2 : d->Ly;
+  if (a.y_count <= 0) return QMG_SUCCESS;
+  a.nrows = a.y_count * a.par_count;
+  int sh[2] = {0, 0};
+  bool zero = true;
+  for (int q = 0; q < a.par_count; q++) {
+    const int p = (a.par_count == 2) ? q : a.par_first;
+    const bool cl = (pieces >> p) & 1u, shf = (pieces >> (10 + p)) & 1u;
+    const unsigned hm = (pieces >> (2 + 4 * p)) & 0xFu;
+    sh[q] = (hm == 0xFu) ? (cl ? 1 : (shf ? 0 : 2)) : 0;
+    if (!((pieces >> (12 + p)) & 1u)) zero = false;
+  }
+  const int shape = (a.par_count == 2 && sh[0] != sh[1]) ? 0 : sh[0];
+  if (shape == 0) return QMG_ERR_UNSUPPORTED;
+  if (lhs == rhs && (shape == 1 || a.par_count == 2)) return QMG_ERR_INVALID;
+  const int lps = dtype == QMG_C64 ? 2 : 1;
+  const long lanes = (long)a.hr * lps;
+  dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK), a.nrows > 65535 ? 65535u : (unsigned)a.nrows);
+  hipStream_t st = as_stream(stream);
+  if (dtype == QMG_C64) { if (a.nrhs == 1) launch_wilson_b<double, false>(a, shape, zero, grid, st); else launch_wilson_b<double, true>(a, shape, zero, grid, st); }
+  else { if (a.nrhs == 1) launch_wilson_b<float, false>(a, shape, zero, grid, st); else launch_wilson_b<float, true>(a, shape, zero, grid, st); }
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+}  // extern "C"

@@ -41,6 +41,7 @@ struct Wilson2D : public Stencil2D {
     if (built_rbjacobi) { deallocate_vector(&rbjacobi_cinv); deallocate_vector(&rbjacobi_clover); deallocate_vector(&rbjacobi_hopping); built_rbjacobi = false; }
     // (the reference leaves a built rbj_dagger stencil dangling here, wilson.h:211-225; it is dropped too)
     if (built_rbj_dagger) { deallocate_vector(&rbj_dagger_cinv); deallocate_vector(&rbj_dagger_clover); deallocate_vector(&rbj_dagger_hopping); built_rbj_dagger = false; }
+    set_direct_links(gauge_links, wilson_coeff);   // the ORIGINAL-operator applies go straight from the links (qmg_wilson.hip)
     generated = true;
   }
 

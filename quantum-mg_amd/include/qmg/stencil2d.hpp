@@ -71,6 +71,11 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (direct_usable(cl, ho)) {   // straight from the links where that serves the piece set
+      const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, 1, 0, 0, 1u, 0, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+    }
     if (f32_matrices && cl == clover && ho == hopping) {   // opt-in fp32 storage of the ORIGINAL stencil (enable_f32_matrices)
       d.clover = clover32; d.hopping = hopping32;
       qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat32");
@@ -104,6 +109,34 @@ struct Stencil2D {
   } f32;
   enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2 };
 
+  // Operators whose stencil is a fixed spin pattern times the gauge links (Wilson2D) can be applied straight from the links
+  // (qmg_wilson_apply_direct, csrc/qmg_wilson.hip: 96 B/site instead of 384, bit-identical to the stored stencil through the
+  // site kernel).  The operator class keeps its own copy of the links here; the ORIGINAL-operator applies take this route for
+  // the piece sets it serves while no variant is swapped in, everything else streams the stored matrices.
+  // QMG_WILSON_DIRECT=0 in the environment turns it off.
+  struct DirectLinks {
+    complex<double>* gauge; void* gauge32; double w; bool on;
+  } direct;
+  bool direct_usable(const complex<double>* cl, const complex<double>* ho) const {
+    return direct.on && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
+  }
+  void set_direct_links(const complex<double>* gauge_links, double w) {   // copies the links (the caller's array may change)
+    static const bool enabled = !(getenv("QMG_WILSON_DIRECT") && atoi(getenv("QMG_WILSON_DIRECT")) == 0);
+    const size_t n = (size_t)2 * lat->get_volume();
+    if (!enabled || lat->get_nc() != 2) { direct.on = false; return; }
+    if (!direct.gauge) direct.gauge = allocate_vector<complex<double>>(n);
+    if (!direct.gauge) { direct.on = false; return; }
+    qmg::ok(qmg_memcpy_d2d(direct.gauge, gauge_links, sizeof(complex<double>) * n, qmg::current_stream()), "qmg_memcpy_d2d");
+    if (direct.gauge32) qmg::ok(qmg_convert(direct.gauge32, QMG_C32, direct.gauge, QMG_C64, n, qmg::current_stream()), "qmg_convert");
+    direct.w = w;
+    direct.on = true;
+  }
+  void drop_direct_links() {
+    if (direct.gauge) deallocate_vector(&direct.gauge);
+    if (direct.gauge32) { qmg_free(direct.gauge32); direct.gauge32 = 0; }
+    direct.on = false;
+  }
+
   bool built_dagger;
   complex<double>*dagger_clover, *dagger_hopping, *dagger_twolink, *dagger_corner;
   bool built_rbjacobi;
@@ -134,6 +167,7 @@ struct Stencil2D {
     eo_cvector = 0;
     f32_matrices = false; clover32 = hopping32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
+    direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false;
     f32.clover16 = f32.hopping16 = f32.rbj_hopping16 = 0; f32.half_on = false;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
@@ -150,6 +184,7 @@ struct Stencil2D {
     for (auto p : all) if (*p != 0) deallocate_vector(p);
     disable_f32_matrices();
     disable_f32_shadow();
+    drop_direct_links();
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
   }
 
@@ -174,6 +209,11 @@ struct Stencil2D {
       good = dup16(&f32.clover16, clover, lat->get_size_cm_l()) && dup16(&f32.hopping16, hopping, lat->get_size_hopping_l());
       if (good && built_rbjacobi) good = dup16(&f32.rbj_hopping16, rbjacobi_hopping, lat->get_size_hopping_l());
       f32.half_on = good;
+    }
+    if (good && direct.on && !direct.gauge32) {   // the links of a direct-apply operator in fp32 as well (8 B/site)
+      const size_t n = (size_t)2 * lat->get_volume();
+      if (qmg_malloc(&direct.gauge32, n * 8) == QMG_SUCCESS) qmg::ok(qmg_convert(direct.gauge32, QMG_C32, direct.gauge, QMG_C64, n, qmg::current_stream()), "qmg_convert");
+      else direct.gauge32 = 0;
     }
     if (!good) { disable_f32_shadow(); return false; }
     f32.on = true;
@@ -350,6 +390,12 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (sizeof(T) == sizeof(double) || direct.gauge32)) {
+      const int rc = qmg_wilson_apply_direct(sizeof(T) == sizeof(float) ? QMG_C32 : QMG_C64, &d, sizeof(T) == sizeof(float) ? direct.gauge32 : (void*)direct.gauge,
+                                             d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, nrhs, stride, 0, mask, 0, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+    }
     if (sizeof(T) == sizeof(float)) {
       if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
       if (f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices, fp32 vectors
@@ -376,13 +422,7 @@ struct Stencil2D {
   // lhs_k = M rhs_k for the active systems of a lock-step batch (<= 16 vectors `stride` apart): one read of the matrices;
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
   void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {
-    qmg_stencil_desc d = desc();
-    if (f32_matrices) {
-      d.clover = clover32; d.hopping = hopping32;
-      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, QMG_P_ALL | QMG_P_ZERO, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
-      return;
-    }
-    qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, QMG_P_ALL | QMG_P_ZERO, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
+    launch_set_batch<double>(QMG_P_ALL | QMG_P_ZERO, lhs, rhs, QMG_ARR_ORIGINAL, shift, eo_shift, dof_shift, nrhs, stride, mask);
   }
 
   complex<double> get_shift() { return shift; }

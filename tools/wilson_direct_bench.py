@@ -1,0 +1,33 @@
+"""Kernel W (Wilson straight from the links, csrc/qmg_wilson.hip) against the stored-stencil kernels at 4096^2 and 2048^2."""
+import importlib, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+qmg = importlib.import_module("quantum-mg_amd"); qmg.init(0)
+t = qmg.Timer()
+def run(fn, nbytes, label):
+    for _ in range(5): fn()
+    qmg.sync(); t.start()
+    for _ in range(50): fn()
+    ms = t.stop_ms() / 50
+    print("%-58s %.4f ms %6.0f GB/s  %.3f of 8 TB/s" % (label, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000), flush=True)
+FULL, DEO = qmg.P_ALL | qmg.P_ZERO, qmg.P_EO | qmg.P_ZERO_E
+for L in (4096, 2048):
+    vol = L * L
+    rng = np.random.default_rng(1)
+    g = qmg.DeviceArray.from_host(np.exp(1j * rng.uniform(-np.pi, np.pi, size=2 * vol)))
+    g32 = qmg.DeviceArray(2 * vol, np.complex64); qmg.convert(g32, qmg.C32, g, qmg.C64, 2 * vol)
+    cl, hp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
+    qmg.wilson_fill(cl, hp, g, L, L, 1.0)
+    d = qmg.make_desc(L, L, 2, cl, hp, -0.07)
+    r, l = qmg.DeviceArray(2 * vol), qmg.DeviceArray(2 * vol); qmg.gaussian(r, 2 * vol, 5)
+    run(lambda: qmg.stencil_apply(d, l, r, FULL), 384 * vol, "L=%d fp64 stored stencil (kernel A), 384 B/site" % L)
+    run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, FULL), 96 * vol, "L=%d fp64 from the links (kernel W), 96 B/site" % L)
+    run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, DEO), 80 * vol / 2, "L=%d fp64 from the links, D_eo, 80 B/site" % L)
+    del cl, hp
+    r32, l32 = qmg.DeviceArray(2 * vol, np.complex64), qmg.DeviceArray(2 * vol, np.complex64)
+    qmg.convert(r32, qmg.C32, r, qmg.C64, 2 * vol)
+    run(lambda: qmg.wilson_apply_direct(qmg.C32, d, g32, l32, r32, FULL), 48 * vol, "L=%d fp32 from the links, 48 B/site" % L)
+    K = 8 if L == 2048 else 4
+    rb, lb = qmg.DeviceArray(2 * vol * K), qmg.DeviceArray(2 * vol * K); qmg.gaussian(rb, 2 * vol * K, 6)
+    run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, lb, rb, FULL, 1.0, K, 2 * vol, (1 << K) - 1), (32 + 64 * K) * vol, "L=%d fp64 from the links, %d systems" % (L, K))
+    del g, g32, r, l, r32, l32, rb, lb
