@@ -381,6 +381,50 @@ def f32_fine_apply(qmg, L, fixture, steps, warmup, barrier):
     return out
 
 
+def wilson_from_links(qmg, L, fixture, steps, warmup, barrier):
+    """The same operator and lattice as the headline, applied straight from the gauge links (qmg_wilson_apply_direct, csrc/qmg_wilson.hip):
+    no stored matrices, 96 B/site in fp64 (links 32 + rhs 32 + lhs 32) and 48 B/site in fp32 -- the route Wilson2D's applies take inside
+    the solvers.  Reported BESIDE the headline, which stays the reference's algorithm (a general stored stencil, 384 B/site).  Gates: the
+    fp64 oracle on the stored stencil, through periodicity, 1e-13 (fp32: 5e-6)."""
+    import oracle_lib as ol
+    vol = L * L
+    g = qmg.DeviceArray.from_host(tiled_gauge(L, fixture))
+    g32 = qmg.DeviceArray(2 * vol, np.complex64)
+    qmg.convert(g32, qmg.C32, g, qmg.C64, 2 * vol)
+    ph = np.loadtxt(fixture)
+    clover, hopping = ol.wilson_fill(ol.phases_to_gauge_u1(ph, 64, 64), 64, 64)
+    rng = np.random.default_rng(1337)
+    v = rng.standard_normal(64 * 64 * 2) + 1j * rng.standard_normal(64 * 64 * 2)
+    want = tile_vector(ol.stencil_apply(ol.make_desc(64, 64, 2, clover, hopping, MASS), v), L, 2)
+    d = qmg.make_desc(L, L, 2, None, None, MASS)
+    out = {"workload": "Wilson apply_M straight from the U(1) links, %dx%d, nc=2 (no stored stencil)" % (L, L)}
+    for name, dtype, gauge, np_t, bytes_site, tol in (("fp64", qmg.C64, g, np.complex128, 96, 1e-13), ("fp32", qmg.C32, g32, np.complex64, 48, 5e-6)):
+        rhs = qmg.DeviceArray.from_host(tile_vector(v, L, 2).astype(np_t))
+        lhs = qmg.DeviceArray(2 * vol, np_t)
+
+        class W:
+            def step(self_inner):
+                qmg.wilson_apply_direct(dtype, d, gauge, lhs, rhs, qmg.P_ALL | qmg.P_ZERO)
+        w = W()
+        w.step()
+        err = float(np.linalg.norm(lhs.to_host().astype(np.complex128) - want) / np.linalg.norm(want))
+        if not err < tol:
+            raise SystemExit("from-the-links parity gate failed (%s, L=%d): rel L2 error %.3e" % (name, L, err))
+        wall, kern_ms = timed(qmg, w, steps, warmup, barrier)
+        out[name] = {"gflops": vol * FLOP_PER_SITE * steps / wall / 1e9, "ms_per_step": wall / steps * 1e3, "parity_gate_rel_l2_vs_fp64_oracle": err,
+                     "speedup_over_the_stored_stencil_bytes": (384 if name == "fp64" else 192) / bytes_site,
+                     "roofline": {"bound": "hbm", "achieved": bytes_site * vol / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": bytes_site * vol / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "kernel": "k_wilson_direct<%s,1,true,false>" % ("double" if name == "fp64" else "float"),
+                                  "algorithmic_bytes_per_launch": bytes_site * vol, "avg_launch_ms": kern_ms,
+                                  "note": "%d B/site: links %d (each link serves the two sites it joins) + rhs + lhs" % (bytes_site, bytes_site // 3)}}
+        rhs.free()
+        lhs.free()
+    g.free()
+    g32.free()
+    return out
+
+
 def staggered_8rhs(qmg, L, fixture, steps, warmup, barrier, torch):
     """BASELINE configs[3] per-GPU workload on this one GPU: staggered 4096^2, 8 right-hand sides sharing one matrix read,
     per-RHS norm2sq, and the (here one-rank) all-reduce slot buffer."""
@@ -679,6 +723,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_also:
         out["also_f32"] = f32_fine_apply(qmg, L, fixture, args.steps, args.warmup, barrier)
+        out["also_wilson_from_links"] = wilson_from_links(qmg, L, fixture, args.steps, args.warmup, barrier)
         out["also_staggered_8rhs"] = staggered_8rhs(qmg, 4096, fixture, max(10, args.steps // 4), args.warmup, barrier, torch)
 
     if rank == 0 and world == 1 and not args.no_also and not args.no_kcycle:

@@ -8,6 +8,8 @@
 //     boundary rows from the received halos (qmg_stencil_apply_slab);
 //   * the reductions: qmg_comm_set_distributed_reductions(1) makes norm2sq / dot / multidot ... of the library return the
 //     sum over ranks, so the Krylov solvers of krylov.hpp run unchanged and take identical decisions on every rank.
+// The operator is applied straight from the gauge links (qmg_wilson_apply_direct: the links are 32 B/site and replicated on
+// every rank, a slab stores no stencil at all); QMG_WILSON_DIRECT=0 switches to the slab's rows of the stored stencil.
 // One rank (no communicator): the exchange degenerates to device copies and the slab is the whole lattice.
 // This round covers the fine Wilson operator (nc = 2) in fp64: one strong-scaled Krylov solve.  The K-cycle's coarse levels
 // need the same halo step in the generic-nc kernels and a halo of the null vectors in the block-local Galerkin build.
@@ -48,17 +50,24 @@ class SlabWilson2D {
   qmg_stencil_desc desc;
   void *comm_stream = nullptr, *ev_rhs = nullptr, *ev_halo = nullptr;
   bool overlap = true;               // false: exchange, then one launch over all rows
+  bool from_links = true;            // apply straight from the (replicated, global) links: qmg_wilson_apply_direct; false: the slab's stored stencil
+  const complex<double>* gauge = nullptr;
+  double w = 1.0;
   long applies = 0;
 
   // gauge_global: the U(1) links of the WHOLE lattice on the device (32 B/site; every rank holds them)
   SlabWilson2D(const SlabGeometry& g, double mass, const complex<double>* gauge_global, double wilson_coeff = 1.0) : geo(g) {
     lat = new Lattice2D(g.Lx, g.Ly_local, 2);
     const size_t vol = (size_t)g.Lx * g.Ly_local;
-    clover = allocate_vector<complex<double>>(4 * vol);
-    hopping = allocate_vector<complex<double>>(16 * vol);
+    gauge = gauge_global; w = wilson_coeff;
+    from_links = !(getenv("QMG_WILSON_DIRECT") && atoi(getenv("QMG_WILSON_DIRECT")) == 0);
     halo_lo = allocate_vector<complex<double>>(2 * (size_t)g.Lx);   // [parity][Lx/2][2]
     halo_hi = allocate_vector<complex<double>>(2 * (size_t)g.Lx);
-    ok(qmg_wilson_fill_slab(clover, hopping, gauge_global, g.Lx, g.Ly_global, g.y0, g.Ly_local, wilson_coeff, current_stream()), "qmg_wilson_fill_slab");
+    if (!from_links) {   // the slab's rows of the stored stencil (384 B/site) instead of the replicated links (the caller keeps gauge_global alive either way)
+      clover = allocate_vector<complex<double>>(4 * vol);
+      hopping = allocate_vector<complex<double>>(16 * vol);
+      ok(qmg_wilson_fill_slab(clover, hopping, gauge_global, g.Lx, g.Ly_global, g.y0, g.Ly_local, wilson_coeff, current_stream()), "qmg_wilson_fill_slab");
+    }
     desc.Lx = g.Lx; desc.Ly = g.Ly_local; desc.nc = 2;
     desc.clover = clover; desc.hopping = hopping;
     desc.shift[0] = mass; desc.shift[1] = 0.0;
@@ -70,12 +79,22 @@ class SlabWilson2D {
   ~SlabWilson2D() {
     qmg_stream_sync(current_stream());
     qmg_stream_sync(comm_stream);
-    deallocate_vector(&clover); deallocate_vector(&hopping); deallocate_vector(&halo_lo); deallocate_vector(&halo_hi);
+    if (clover) deallocate_vector(&clover);
+    if (hopping) deallocate_vector(&hopping);
+    deallocate_vector(&halo_lo); deallocate_vector(&halo_hi);
     qmg_event_destroy(ev_rhs); qmg_event_destroy(ev_halo); qmg_stream_destroy(comm_stream);
     delete lat;
   }
   size_t size_cv() const { return (size_t)lat->get_size_cv(); }
 
+  // one launch over the rows `rows` selects (0 all, 1 interior, 2 boundary)
+  void launch_rows(complex<double>* lhs, complex<double>* rhs, unsigned pieces, int rows, void* st) {
+    const size_t hs = 2 * (size_t)geo.Lx;
+    if (from_links)
+      ok(qmg_wilson_apply_direct(QMG_C64, &desc, gauge, geo.Ly_global, geo.y0, w, lhs, rhs, halo_lo, halo_hi, pieces, 1, 0, hs, 1u, rows, st), "qmg_wilson_apply_direct");
+    else
+      ok(qmg_stencil_apply_slab(QMG_C64, &desc, lhs, rhs, halo_lo, halo_hi, pieces, 1, 0, hs, 1u, rows, st), "qmg_stencil_apply_slab");
+  }
   // lhs = pieces(M) rhs on the slab; rhs must not alias lhs
   void apply(complex<double>* lhs, complex<double>* rhs, unsigned pieces) {
     void* st = current_stream();
@@ -83,7 +102,7 @@ class SlabWilson2D {
     applies++;
     if (!overlap) {
       ok(qmg_halo_exchange(QMG_C64, rhs, geo.Lx, geo.Ly_local, 2, halo_lo, halo_hi, 1, 0, hs, st), "qmg_halo_exchange");
-      ok(qmg_stencil_apply_slab(QMG_C64, &desc, lhs, rhs, halo_lo, halo_hi, pieces, 1, 0, hs, 1u, 0, st), "qmg_stencil_apply_slab");
+      launch_rows(lhs, rhs, pieces, 0, st);
       return;
     }
     // the exchange on its own stream, behind the producer of rhs; the interior rows meanwhile; the boundary rows after both
@@ -91,9 +110,9 @@ class SlabWilson2D {
     ok(qmg_stream_wait_event(comm_stream, ev_rhs), "qmg_stream_wait_event");
     ok(qmg_halo_exchange(QMG_C64, rhs, geo.Lx, geo.Ly_local, 2, halo_lo, halo_hi, 1, 0, hs, comm_stream), "qmg_halo_exchange");
     ok(qmg_event_record(ev_halo, comm_stream), "qmg_event_record");
-    ok(qmg_stencil_apply_slab(QMG_C64, &desc, lhs, rhs, halo_lo, halo_hi, pieces, 1, 0, hs, 1u, 1, st), "qmg_stencil_apply_slab");
+    launch_rows(lhs, rhs, pieces, 1, st);
     ok(qmg_stream_wait_event(st, ev_halo), "qmg_stream_wait_event");
-    ok(qmg_stencil_apply_slab(QMG_C64, &desc, lhs, rhs, halo_lo, halo_hi, pieces, 1, 0, hs, 1u, 2, st), "qmg_stencil_apply_slab");
+    launch_rows(lhs, rhs, pieces, 2, st);
     // the next exchange overwrites the halos: it is ordered behind this boundary launch through ev_rhs of the next apply
   }
   void apply_M(complex<double>* lhs, complex<double>* rhs) { apply(lhs, rhs, QMG_P_ALL | QMG_P_ZERO); }
