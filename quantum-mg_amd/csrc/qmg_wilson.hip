@@ -53,6 +53,19 @@ __device__ __forceinline__ void fmac2w(R& ax, R& ay, R mx, R my, R bx, R by) {
   ay = fma(mx, by, ay); ay = fma(my, bx, ay);
 }
 
+// a row-uniform pointer, told to the compiler: the loads then take the scalar-base + 32-bit-offset form
+// (the result is a GLOBAL-address-space pointer: an integer cast to a plain pointer would make the accesses flat_load / flat_store)
+typedef __attribute__((address_space(1))) char gchar;
+__device__ __forceinline__ gchar* uni(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gchar*)(((unsigned long long)hi << 32) | lo);
+}
+template <typename V> __device__ __forceinline__ V gld(const gchar* base, unsigned off) { return *(const __attribute__((address_space(1))) V*)(base + off); }
+template <typename V> __device__ __forceinline__ V gld_nt(const gchar* base, unsigned off) {
+  return __builtin_nontemporal_load((const __attribute__((address_space(1))) V*)(base + off));
+}
+
 // the four hop matrices' entries [row][col] for column c from the links (k_wilson_fill's multiplications, qmg_fill.hip)
 template <typename R>
 struct HopCol { R m0x, m0y, m1x, m1y; };   // entry (row 0, col c) and (row 1, col c)
@@ -93,55 +106,61 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
     const int y = a.boundary_only ? (yi ? a.Ly - 1 : 0) : a.y_first + yi;
     const bool do_shift = (a.pieces >> (10 + p)) & 1u;
     const bool do_zero = ZERO || ((a.pieces >> (12 + p)) & 1u);
-    const long site = (long)p * a.half_vol + (long)y * a.hr + j;
-    const long opp = (long)(1 - p) * a.half_vol;
     const int s = (y + p) & 1;
     int jp = j + s;     if (jp == a.hr) jp = 0;
     int jm = j + s - 1; if (jm < 0) jm = a.hr - 1;
     const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
     const int ym = (y == 0) ? a.Ly - 1 : y - 1;
-    const long nb[4] = {opp + (long)y * a.hr + jp, opp + (long)yp * a.hr + j, opp + (long)y * a.hr + jm, opp + (long)ym * a.hr + j};
+    // Addresses = a row-uniform 64-bit base (SGPRs) + a 32-bit lane offset: the loads take the scalar-base form and an
+    // address costs one VGPR instead of two (a half-row is far below 4 GiB).
+    constexpr unsigned CH = 16u * LPS;                             // bytes of a site vector
+    const unsigned off_j = (unsigned)j * CH + (unsigned)c0 * 16u, off_jp = (unsigned)jp * CH + (unsigned)c0 * 16u, off_jm = (unsigned)jm * CH + (unsigned)c0 * 16u;
+    const long row_own = ((long)p * a.half_vol + (long)y * a.hr) * CH;
+    const long opp = (long)(1 - p) * a.half_vol;
+    const long row_x = (opp + (long)y * a.hr) * CH, row_yp = (opp + (long)yp * a.hr) * CH, row_ym = (opp + (long)ym * a.hr) * CH;
+    const long hrow = (long)(1 - p) * a.hr * CH;                   // the halo buffers' row of the opposite parity
     // links on the global lattice
     const int gy = a.gy0 + y;
     const int gym = (gy == 0) ? a.gLy - 1 : gy - 1;
     const long gvol = 2 * a.ghalf_vol;
-    const long gsite = (long)p * a.ghalf_vol + (long)gy * a.hr + j;
-    const long gxm = (long)(1 - p) * a.ghalf_vol + (long)gy * a.hr + jm;
-    const long gymi = (long)(1 - p) * a.ghalf_vol + (long)gym * a.hr + j;
-    const T* g = reinterpret_cast<const T*>(a.gauge);
+    constexpr unsigned GB = 2u * sizeof(T);                        // bytes of a link
+    const char* gc = reinterpret_cast<const char*>(a.gauge);
+    const gchar* g_own_x = uni(gc + ((long)p * a.ghalf_vol + (long)gy * a.hr) * GB);
+    const gchar* g_own_y = uni(gc + (gvol + (long)p * a.ghalf_vol + (long)gy * a.hr) * GB);
+    const gchar* g_xm = uni(gc + ((long)(1 - p) * a.ghalf_vol + (long)gy * a.hr) * GB);
+    const gchar* g_ym = uni(gc + (gvol + (long)(1 - p) * a.ghalf_vol + (long)gym * a.hr) * GB);
+    const unsigned goff_j = (unsigned)j * GB, goff_jm = (unsigned)jm * GB;
     // ---- load phase: first system's chunks, then the four links (raw)
     const bool from_hi = a.halo_hi && y + 1 == a.Ly, from_lo = a.halo_lo && y == 0;
-    const long hsite = (long)(1 - p) * a.hr + j;
     w4f xr[5];                                     // neighbours +x +y -x -y, own
     auto load_x = [&](int k) {
       const long off = (long)a.ridx[k] * sys_bytes;
       const char* x = reinterpret_cast<const char*>(a.rhs) + off;
       const long hoff = (long)a.ridx[k] * a.halo_stride * (long)(2 * sizeof(T));
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const char* base = x;
-        long idx = nb[d];
-        if (d == 1 && from_hi) { base = reinterpret_cast<const char*>(a.halo_hi) + hoff; idx = hsite; }
-        if (d == 3 && from_lo) { base = reinterpret_cast<const char*>(a.halo_lo) + hoff; idx = hsite; }
-        xr[d] = *(reinterpret_cast<const w4f*>(base) + idx * LPS + c0);
-      }
-      if (SHAPE == 1 || do_shift) xr[4] = *(reinterpret_cast<const w4f*>(x) + site * LPS + c0);
+      const gchar* b1 = uni(from_hi ? reinterpret_cast<const char*>(a.halo_hi) + hoff + hrow : x + row_yp);
+      const gchar* b3 = uni(from_lo ? reinterpret_cast<const char*>(a.halo_lo) + hoff + hrow : x + row_ym);
+      const gchar* bx = uni(x + row_x);
+      xr[0] = gld<w4f>(bx, off_jp);
+      xr[1] = gld<w4f>(b1, off_j);
+      xr[2] = gld<w4f>(bx, off_jm);
+      xr[3] = gld<w4f>(b3, off_j);
+      if (SHAPE == 1 || do_shift) xr[4] = gld<w4f>(uni(x + row_own), off_j);
     };
     load_x(0);
     R lx[4], ly[4];                                // links per direction, conjugated for the backward ones
     if (F64) {
-      const w2d u0 = __builtin_nontemporal_load(reinterpret_cast<const w2d*>(g) + gsite);
-      const w2d u1 = __builtin_nontemporal_load(reinterpret_cast<const w2d*>(g) + gvol + gsite);
-      const w2d u2 = *(reinterpret_cast<const w2d*>(g) + gxm);
-      const w2d u3 = *(reinterpret_cast<const w2d*>(g) + gvol + gymi);
+      const w2d u0 = gld_nt<w2d>(g_own_x, goff_j);
+      const w2d u1 = gld_nt<w2d>(g_own_y, goff_j);
+      const w2d u2 = gld<w2d>(g_xm, goff_jm);
+      const w2d u3 = gld<w2d>(g_ym, goff_j);
       __builtin_amdgcn_sched_barrier(0);
       lx[0] = (R)u0.x; ly[0] = (R)u0.y; lx[1] = (R)u1.x; ly[1] = (R)u1.y;
       lx[2] = (R)u2.x; ly[2] = -(R)u2.y; lx[3] = (R)u3.x; ly[3] = -(R)u3.y;
     } else {
-      const w2f u0 = __builtin_nontemporal_load(reinterpret_cast<const w2f*>(g) + gsite);
-      const w2f u1 = __builtin_nontemporal_load(reinterpret_cast<const w2f*>(g) + gvol + gsite);
-      const w2f u2 = *(reinterpret_cast<const w2f*>(g) + gxm);
-      const w2f u3 = *(reinterpret_cast<const w2f*>(g) + gvol + gymi);
+      const w2f u0 = gld_nt<w2f>(g_own_x, goff_j);
+      const w2f u1 = gld_nt<w2f>(g_own_y, goff_j);
+      const w2f u2 = gld<w2f>(g_xm, goff_jm);
+      const w2f u3 = gld<w2f>(g_ym, goff_j);
       __builtin_amdgcn_sched_barrier(0);
       lx[0] = (R)u0.x; ly[0] = (R)u0.y; lx[1] = (R)u1.x; ly[1] = (R)u1.y;
       lx[2] = (R)u2.x; ly[2] = -(R)u2.y; lx[3] = (R)u3.x; ly[3] = -(R)u3.y;
@@ -191,14 +210,14 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
         w2d o;
         o.x = c ? (recvx + ownx) : (ownx + recvx);
         o.y = c ? (recvy + owny) : (owny + recvy);
-        w2d* dst = reinterpret_cast<w2d*>(out) + site * 2 + c;
+        __attribute__((address_space(1))) w2d* dst = (__attribute__((address_space(1))) w2d*)(uni(out + row_own) + off_j);
         if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
         __builtin_nontemporal_store(o, dst);
       } else {
         w4f o;
         o.x = (float)(ax[0][0] + ax[NCOL - 1][0]); o.y = (float)(ay[0][0] + ay[NCOL - 1][0]);
         o.z = (float)(ax[0][1] + ax[NCOL - 1][1]); o.w = (float)(ay[0][1] + ay[NCOL - 1][1]);
-        w4f* dst = reinterpret_cast<w4f*>(out) + site;
+        __attribute__((address_space(1))) w4f* dst = (__attribute__((address_space(1))) w4f*)(uni(out + row_own) + off_j);
         if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
         __builtin_nontemporal_store(o, dst);
       }
