@@ -62,29 +62,43 @@ if want("fine"):
         vol = L * L
         wl = bench.Workload(qmg, L, fixture, 1337)
         ms = timeit(wl.step, reps=50, warm=10)
-        row("k_stencil_pair<double,2,2> Wilson %d^2 fp64" % L, ms, 384 * vol, "headline kernel (re-check after templating on the storage scalar)")
+        row("k_stencil_pair<double,2,2> Wilson %d^2 fp64" % L, ms, 384 * vol, "headline kernel: the reference's algorithm, a general stored stencil")
         c32, h32 = qmg.DeviceArray(4 * vol, np.complex64), qmg.DeviceArray(16 * vol, np.complex64)
         qmg.convert(c32, qmg.C32, wl.clover, qmg.C64, 4 * vol)
         qmg.convert(h32, qmg.C32, wl.hopping, qmg.C64, 16 * vol)
         r32, l32 = gauss(2 * vol, 7, qmg.C32), qmg.DeviceArray(2 * vol, np.complex64)
         d32 = qmg.make_desc(L, L, 2, c32, h32, bench.MASS)
-        for nt in (3, 0):
-            qmg.set_tuning("stencil_nt", nt)
-            ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
-            row("k_stencil_pair<float,2,2> Wilson %d^2 fp32 (stencil_nt=%d)" % (L, nt), ms, 192 * vol, "192 B/site: fp32 matrices AND vectors, fp32 arithmetic")
-        qmg.set_tuning("stencil_nt", 3)
+        ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
+        row("k_stencil_site<1,...> (kernel S) Wilson %d^2 fp32" % L, ms, 192 * vol, "192 B/site: fp32 matrices AND vectors, fp32 arithmetic")
+        qmg.set_tuning("stencil_site", 0)
+        ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
+        row("k_stencil_elem<float,2> (kernel A in fp32, stencil_site=0) Wilson %d^2 fp32" % L, ms, 192 * vol, "the kernel S replaced")
+        qmg.set_tuning("stencil_site", 3)
+        # straight from the links (kernel W): no stored stencil
+        rng = np.random.default_rng(1)
+        g64 = qmg.DeviceArray.from_host(np.exp(1j * rng.uniform(-np.pi, np.pi, size=2 * vol)))
+        g32 = qmg.DeviceArray(2 * vol, np.complex64)
+        qmg.convert(g32, qmg.C32, g64, qmg.C64, 2 * vol)
+        dW = qmg.make_desc(L, L, 2, None, None, bench.MASS)
+        ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C64, dW, g64, wl.lhs, wl.rhs, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
+        row("k_wilson_direct<double> (kernel W) Wilson %d^2 fp64, from the links" % L, ms, 96 * vol, "96 B/site: links 32 + rhs 32 + lhs 32; bit-identical to the stored stencil")
+        ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C64, dW, g64, wl.lhs, wl.rhs, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
+        row("k_wilson_direct<double> D_eo %d^2 fp64" % L, ms, 80 * vol / 2, "one parity: links 32 + rhs 32 + lhs 16 per written site... counted as 80 B per written site")
+        ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C32, dW, g32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
+        row("k_wilson_direct<float> (kernel W) Wilson %d^2 fp32, from the links" % L, ms, 48 * vol, "48 B/site")
+        g64.free(); g32.free()
         c16, h16 = qmg.DeviceArray(4 * vol, np.float32), qmg.DeviceArray(16 * vol, np.float32)
         qmg.convert_to_c16(c16, wl.clover, qmg.C64, 4 * vol)
         qmg.convert_to_c16(h16, wl.hopping, qmg.C64, 16 * vol)
         d16 = qmg.make_desc(L, L, 2, c16, h16, bench.MASS)
         ms = timeit(lambda: qmg.stencil_apply_h16(d16, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
-        row("k_stencil_h16 Wilson %d^2, complex<half> matrices + complex<float> vectors" % L, ms, 112 * vol, "112 B/site: 16-bit stored operator (preconditioner only)")
+        row("k_stencil_site<0,...> (kernel S) Wilson %d^2, complex<half> matrices + complex<float> vectors" % L, ms, 112 * vol, "112 B/site: 16-bit stored operator (preconditioner only)")
         ms = timeit(lambda: qmg.stencil_apply_h16(d16, l32, r32, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
-        row("k_stencil_h16 D_eo %d^2" % L, ms, (4 * 16 + 16 + 16) * vol / 2, "one parity")
+        row("k_stencil_site<0,2,...> D_eo %d^2, 16-bit matrices" % L, ms, (4 * 16 + 16 + 16) * vol / 2, "one parity")
         c16.free(); h16.free()
         # one-parity (Schur) applies
         ms = timeit(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
-        row("k_stencil_elem<float,2> D_eo %d^2 fp32" % L, ms, (4 * 32 + 16 + 16) * vol / 2, "one parity: 4 hopping matrices + rhs + lhs")
+        row("k_stencil_site<1,2,...> D_eo %d^2 fp32" % L, ms, (4 * 32 + 16 + 16) * vol / 2, "one parity: 4 hopping matrices + rhs + lhs")
         for a in (c32, h32, r32, l32):
             a.free()
         wl.free()
