@@ -1100,6 +1100,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "mfma_vl")) { g_mfma_vl = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_tile")) { g_xfer_tile = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_pack")) { g_xfer_pack = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "wilson_pair")) { g_wilson_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "setup_fused")) { g_setup_fused = value; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }

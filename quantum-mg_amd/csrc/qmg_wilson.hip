@@ -19,9 +19,13 @@
 // only (D_eo / D_oe); anything else returns QMG_ERR_UNSUPPORTED and the caller uses the stored stencil.
 // y-slabs: the links are indexed on the GLOBAL lattice (replicated, 32 B/site), only the right-hand side's rows
 // -1 / Ly come from halo buffers.
+#include <type_traits>
+
 #include "qmg_common.h"
 
 namespace qmg {
+
+int g_wilson_pair = 1;   // tuning knob "wilson_pair": the full operator through the paired-parity kernel W2
 
 struct WilsonArgs {
   const void* gauge;       // [mu][global site] complex<T>
@@ -88,12 +92,72 @@ __device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw) {
   return o;
 }
 
+// One site's (fp64: one site's column c0) result from its five right-hand-side chunks xr = {+x, +y, -x, -y, own} and its four
+// links (backward ones already conjugated), then the store.  The order of operations is kernel S's (qmg_site.hip).
+template <typename T, int SHAPE>
+__device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4], const T (&ly)[4], T hw, T cw, bool do_shift, bool do_zero, int p, int c0,
+                                            const WilsonArgs& a, gchar* dst_chunk) {
+  constexpr bool F64 = sizeof(T) == 8;
+  constexpr int NCOL = F64 ? 1 : 2;
+  typedef T R;
+  // acc[col][row]: column `col`'s contribution to output row `row` (the site kernel's per-lane partial sums)
+  R ax[NCOL][2], ay[NCOL][2];
+#pragma unroll
+  for (int cc = 0; cc < NCOL; cc++) { ax[cc][0] = ax[cc][1] = ay[cc][0] = ay[cc][1] = (R)0; }
+#pragma unroll
+  for (int cc = 0; cc < NCOL; cc++) {
+    const int c = F64 ? c0 : cc;
+    // component c of a chunk: fp64 chunk = that component; fp32 chunk = (x0.re, x0.im, x1.re, x1.im)
+    auto comp = [&](const w4f& v, R& vx, R& vy) {
+      if (F64) { const w2d q = __builtin_bit_cast(w2d, v); vx = (R)q.x; vy = (R)q.y; }
+      else { vx = (R)(c ? v.z : v.x); vy = (R)(c ? v.w : v.y); }
+    };
+    R vx, vy;
+    if (SHAPE == 1) {   // clover first: 2w on the diagonal (row == col)
+      comp(xr[4], vx, vy);
+      fmac2w<R>(ax[cc][c], ay[cc][c], cw, (R)0, vx, vy);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      comp(xr[d], vx, vy);
+      const HopCol<R> m = hop_col<R>(d, c, lx[d], ly[d], hw);
+      fmac2w<R>(ax[cc][0], ay[cc][0], m.m0x, m.m0y, vx, vy);
+      fmac2w<R>(ax[cc][1], ay[cc][1], m.m1x, m.m1y, vx, vy);
+    }
+    if (do_shift) {   // shift +- eo_shift +- dof_shift on the diagonal (stencil_2d.h:890-908)
+      const double sg = p ? -1.0 : 1.0, dg = c ? -1.0 : 1.0;
+      const R sx = (R)(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0]), sy = (R)(a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
+      comp(xr[4], vx, vy);
+      fmac2w<R>(ax[cc][c], ay[cc][c], sx, sy, vx, vy);
+    }
+  }
+  if (F64) {
+    // lane c keeps row c: own column's part + the partner's part of that row
+    const int c = c0;
+    const double sendx = c ? (double)ax[0][0] : (double)ax[0][1], sendy = c ? (double)ay[0][0] : (double)ay[0][1];
+    const double recvx = lane_xor1(sendx), recvy = lane_xor1(sendy);
+    const double ownx = c ? (double)ax[0][1] : (double)ax[0][0], owny = c ? (double)ay[0][1] : (double)ay[0][0];
+    w2d o;
+    o.x = c ? (recvx + ownx) : (ownx + recvx);
+    o.y = c ? (recvy + owny) : (owny + recvy);
+    __attribute__((address_space(1))) w2d* dst = (__attribute__((address_space(1))) w2d*)dst_chunk;
+    if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
+    __builtin_nontemporal_store(o, dst);
+  } else {
+    w4f o;
+    o.x = (float)(ax[0][0] + ax[NCOL - 1][0]); o.y = (float)(ay[0][0] + ay[NCOL - 1][0]);
+    o.z = (float)(ax[0][1] + ax[NCOL - 1][1]); o.w = (float)(ay[0][1] + ay[NCOL - 1][1]);
+    __attribute__((address_space(1))) w4f* dst = (__attribute__((address_space(1))) w4f*)dst_chunk;
+    if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
+    __builtin_nontemporal_store(o, dst);
+  }
+}
+
 // T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only.
 template <typename T, int SHAPE, bool ZERO, bool BATCH>
 __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
-  constexpr int NCOL = F64 ? 1 : 2;                // columns a lane handles
   typedef T R;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
@@ -169,57 +233,92 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
     for (int k = 0; k < nsys; k++) {
       if (BATCH && k > 0) { load_x(k); __builtin_amdgcn_sched_barrier(0); }
       char* out = reinterpret_cast<char*>(a.lhs) + (long)a.ridx[k] * sys_bytes;
-      // acc[col][row]: column `col`'s contribution to output row `row` (the site kernel's per-lane partial sums)
-      R ax[NCOL][2], ay[NCOL][2];
-#pragma unroll
-      for (int cc = 0; cc < NCOL; cc++) { ax[cc][0] = ax[cc][1] = ay[cc][0] = ay[cc][1] = (R)0; }
-#pragma unroll
-      for (int cc = 0; cc < NCOL; cc++) {
-        const int c = F64 ? c0 : cc;
-        // component c of a chunk: fp64 chunk = that component; fp32 chunk = (x0.re, x0.im, x1.re, x1.im)
-        auto comp = [&](const w4f& v, R& vx, R& vy) {
-          if (F64) { const w2d q = __builtin_bit_cast(w2d, v); vx = (R)q.x; vy = (R)q.y; }
-          else { vx = (R)(c ? v.z : v.x); vy = (R)(c ? v.w : v.y); }
-        };
-        R vx, vy;
-        if (SHAPE == 1) {   // clover first: 2w on the diagonal (row == col)
-          comp(xr[4], vx, vy);
-          fmac2w<R>(ax[cc][c], ay[cc][c], cw, (R)0, vx, vy);
-        }
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          comp(xr[d], vx, vy);
-          const HopCol<R> m = hop_col<R>(d, c, lx[d], ly[d], hw);
-          fmac2w<R>(ax[cc][0], ay[cc][0], m.m0x, m.m0y, vx, vy);
-          fmac2w<R>(ax[cc][1], ay[cc][1], m.m1x, m.m1y, vx, vy);
-        }
-        if (do_shift) {   // shift +- eo_shift +- dof_shift on the diagonal (stencil_2d.h:890-908)
-          const double sg = p ? -1.0 : 1.0, dg = c ? -1.0 : 1.0;
-          const R sx = (R)(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0]), sy = (R)(a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
-          comp(xr[4], vx, vy);
-          fmac2w<R>(ax[cc][c], ay[cc][c], sx, sy, vx, vy);
-        }
+      wilson_site<T, SHAPE>(xr, lx, ly, hw, cw, do_shift, do_zero, p, c0, a, uni(out + row_own) + off_j);
+    }
+  }
+}
+
+// Kernel W2: BOTH parities of column j on row y per lane group -- the full operator (clover + all hops on both parities).
+// Kernel W is not HBM-bound but in-flight-bound (3 KB of HBM requests per wavefront); a pair shares what the two sites
+// have in common -- each site's own chunk is an x-neighbour of the other, one back link is the other's own link: 15 loads
+// per pair instead of 18 -- and puts twice the HBM bytes of a wavefront in flight.  Per-site arithmetic = wilson_site.
+template <typename T, bool ZERO, bool BATCH>
+__global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
+  constexpr bool F64 = sizeof(T) == 8;
+  constexpr int LPS = F64 ? 2 : 1;
+  typedef T R;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
+  if (j >= a.hr) return;
+  const long sys_bytes = a.vec_stride * (long)(2 * sizeof(T));
+  const R hw = (R)(-0.5 * a.w), cw = (R)(2.0 * a.w);
+  constexpr unsigned CH = 16u * LPS, GB = 2u * sizeof(T);
+  const int jl = (j == 0) ? a.hr - 1 : j - 1, jr = (j + 1 == a.hr) ? 0 : j + 1;
+  const unsigned off_j = (unsigned)j * CH + (unsigned)c0 * 16u, off_l = (unsigned)jl * CH + (unsigned)c0 * 16u, off_r = (unsigned)jr * CH + (unsigned)c0 * 16u;
+  const unsigned goff_j = (unsigned)j * GB, goff_l = (unsigned)jl * GB;
+  for (int yi = blockIdx.y; yi < a.y_count; yi += gridDim.y) {
+    const int y = a.boundary_only ? (yi ? a.Ly - 1 : 0) : a.y_first + yi;
+    const int sE = y & 1;                          // the even site of column j sits at x = 2j + sE, the odd one at 2j + 1 - sE
+    const bool shE = (a.pieces >> 10) & 1u, shO = (a.pieces >> 11) & 1u;
+    const bool zE = ZERO || ((a.pieces >> 12) & 1u), zO = ZERO || ((a.pieces >> 13) & 1u);
+    const int yp = (y + 1 == a.Ly) ? 0 : y + 1, ym = (y == 0) ? a.Ly - 1 : y - 1;
+    const long rowE = (long)y * a.hr * CH, rowO = (a.half_vol + (long)y * a.hr) * CH;
+    const long rowE_up = (long)yp * a.hr * CH, rowE_dn = (long)ym * a.hr * CH;
+    const long rowO_up = (a.half_vol + (long)yp * a.hr) * CH, rowO_dn = (a.half_vol + (long)ym * a.hr) * CH;
+    const bool from_hi = a.halo_hi && y + 1 == a.Ly, from_lo = a.halo_lo && y == 0;
+    // the x-neighbour each site does not get from its partner: sE = 0: E's -x (odd row, j-1) and O's +x (even row, j+1); sE = 1: mirrored
+    const unsigned off_oth_O = sE ? off_r : off_l;      // in the ODD row, for the even site
+    const unsigned off_oth_E = sE ? off_l : off_r;      // in the EVEN row, for the odd site
+    w4f ownE, ownO, othO, othE, upE, dnE, upO, dnO;     // upE / dnE: the even site's +y / -y neighbours (odd rows), etc.
+    auto load_x = [&](int k) {
+      const long off = (long)a.ridx[k] * sys_bytes;
+      const char* x = reinterpret_cast<const char*>(a.rhs) + off;
+      const long hoff = (long)a.ridx[k] * a.halo_stride * (long)(2 * sizeof(T));
+      const gchar* bE = uni(x + rowE);
+      const gchar* bO = uni(x + rowO);
+      const long hE = 0, hO = (long)a.hr * CH;          // halo buffers: [parity][hr] site vectors
+      const gchar* bO_up = uni(from_hi ? reinterpret_cast<const char*>(a.halo_hi) + hoff + hO : x + rowO_up);
+      const gchar* bE_up = uni(from_hi ? reinterpret_cast<const char*>(a.halo_hi) + hoff + hE : x + rowE_up);
+      const gchar* bO_dn = uni(from_lo ? reinterpret_cast<const char*>(a.halo_lo) + hoff + hO : x + rowO_dn);
+      const gchar* bE_dn = uni(from_lo ? reinterpret_cast<const char*>(a.halo_lo) + hoff + hE : x + rowE_dn);
+      ownE = gld<w4f>(bE, off_j); ownO = gld<w4f>(bO, off_j);
+      othO = gld<w4f>(bO, off_oth_O); othE = gld<w4f>(bE, off_oth_E);
+      upE = gld<w4f>(bO_up, off_j); dnE = gld<w4f>(bO_dn, off_j);
+      upO = gld<w4f>(bE_up, off_j); dnO = gld<w4f>(bE_dn, off_j);
+    };
+    load_x(0);
+    // links (global lattice): own of both sites, the one back-x link that is not the partner's own, two back-y links
+    const int gy = a.gy0 + y;
+    const int gym = (gy == 0) ? a.gLy - 1 : gy - 1;
+    const long gvol = 2 * a.ghalf_vol;
+    const char* gc = reinterpret_cast<const char*>(a.gauge);
+    const gchar* gxE = uni(gc + ((long)gy * a.hr) * GB);
+    const gchar* gxO = uni(gc + (a.ghalf_vol + (long)gy * a.hr) * GB);
+    const gchar* gyE = uni(gc + (gvol + (long)gy * a.hr) * GB);
+    const gchar* gyO = uni(gc + (gvol + a.ghalf_vol + (long)gy * a.hr) * GB);
+    const gchar* gyE_dn = uni(gc + (gvol + (long)gym * a.hr) * GB);                 // Uy of the EVEN sites of row y-1: the odd site's back-y link
+    const gchar* gyO_dn = uni(gc + (gvol + a.ghalf_vol + (long)gym * a.hr) * GB);   // ... of the ODD sites: the even site's
+    typedef typename std::conditional<F64, w2d, w2f>::type LK;
+    const LK uxE = gld<LK>(gxE, goff_j), uxO = gld<LK>(gxO, goff_j), uyE = gld_nt<LK>(gyE, goff_j), uyO = gld_nt<LK>(gyO, goff_j);
+    const LK ubx = gld<LK>(sE ? gxE : gxO, goff_l);     // sE = 0: Ux of the odd site at j-1 (the even site's back-x); sE = 1: Ux of the even site at j-1
+    const LK ubyE = gld<LK>(gyO_dn, goff_j), ubyO = gld<LK>(gyE_dn, goff_j);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nsys = BATCH ? a.nrhs : 1;
+    for (int k = 0; k < nsys; k++) {
+      if (BATCH && k > 0) { load_x(k); __builtin_amdgcn_sched_barrier(0); }
+      char* out = reinterpret_cast<char*>(a.lhs) + (long)a.ridx[k] * sys_bytes;
+      // even site: +x = odd row at j + sE, -x = odd row at j + sE - 1; odd site: +x = even row at j + 1 - sE, -x = even row at j - sE
+      {   // (the links are unpacked site by site, right before use: fewer live registers than both sets up front)
+        const LK bxE = sE ? uxO : ubx;                   // Ux at the even site's -x neighbour (an odd site at jmE = j + sE - 1)
+        const R lxE[4] = {(R)uxE.x, (R)uyE.x, (R)bxE.x, (R)ubyE.x}, lyE[4] = {(R)uxE.y, (R)uyE.y, -(R)bxE.y, -(R)ubyE.y};
+        const w4f xrE[5] = {sE ? othO : ownO, upE, sE ? ownO : othO, dnE, ownE};
+        wilson_site<T, 1>(xrE, lxE, lyE, hw, cw, shE, zE, 0, c0, a, uni(out + rowE) + off_j);
       }
-      if (F64) {
-        // lane c keeps row c: own column's part + the partner's part of that row
-        const int c = c0;
-        const double sendx = c ? (double)ax[0][0] : (double)ax[0][1], sendy = c ? (double)ay[0][0] : (double)ay[0][1];
-        const double recvx = lane_xor1(sendx), recvy = lane_xor1(sendy);
-        const double ownx = c ? (double)ax[0][1] : (double)ax[0][0], owny = c ? (double)ay[0][1] : (double)ay[0][0];
-        // row r = col0 part + col1 part, in that order (the site kernel adds lane c=0's value and lane c=1's)
-        w2d o;
-        o.x = c ? (recvx + ownx) : (ownx + recvx);
-        o.y = c ? (recvy + owny) : (owny + recvy);
-        __attribute__((address_space(1))) w2d* dst = (__attribute__((address_space(1))) w2d*)(uni(out + row_own) + off_j);
-        if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
-        __builtin_nontemporal_store(o, dst);
-      } else {
-        w4f o;
-        o.x = (float)(ax[0][0] + ax[NCOL - 1][0]); o.y = (float)(ay[0][0] + ay[NCOL - 1][0]);
-        o.z = (float)(ax[0][1] + ax[NCOL - 1][1]); o.w = (float)(ay[0][1] + ay[NCOL - 1][1]);
-        __attribute__((address_space(1))) w4f* dst = (__attribute__((address_space(1))) w4f*)(uni(out + row_own) + off_j);
-        if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
-        __builtin_nontemporal_store(o, dst);
+      {
+        const LK bxO = sE ? ubx : uxE;                   // Ux at the odd site's -x neighbour (an even site at jmO = j - sE)
+        const R lxO[4] = {(R)uxO.x, (R)uyO.x, (R)bxO.x, (R)ubyO.x}, lyO[4] = {(R)uxO.y, (R)uyO.y, -(R)bxO.y, -(R)ubyO.y};
+        const w4f xrO[5] = {sE ? ownE : othE, upO, sE ? othE : ownE, dnO, ownO};
+        wilson_site<T, 1>(xrO, lxO, lyO, hw, cw, shO, zO, 1, c0, a, uni(out + rowO) + off_j);
       }
     }
   }
@@ -291,6 +390,18 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
   const long lanes = (long)a.hr * lps;
   dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK), a.nrows > 65535 ? 65535u : (unsigned)a.nrows);
   hipStream_t st = as_stream(stream);
+  if (shape == 1 && a.par_count == 2 && g_wilson_pair) {   // the full operator: both parities of a column per lane group (kernel W2)
+    dim3 gridp(grid.x, a.y_count > 65535 ? 65535u : (unsigned)a.y_count);
+    if (dtype == QMG_C64) {
+      if (a.nrhs == 1) { if (zero) k_wilson_pair<double, true, false><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, false><<<gridp, BLOCK, 0, st>>>(a); }
+      else { if (zero) k_wilson_pair<double, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, true><<<gridp, BLOCK, 0, st>>>(a); }
+    } else {
+      if (a.nrhs == 1) { if (zero) k_wilson_pair<float, true, false><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<float, false, false><<<gridp, BLOCK, 0, st>>>(a); }
+      else { if (zero) k_wilson_pair<float, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<float, false, true><<<gridp, BLOCK, 0, st>>>(a); }
+    }
+    QMG_LAUNCH_CHECK();
+    return QMG_SUCCESS;
+  }
   if (dtype == QMG_C64) { if (a.nrhs == 1) launch_wilson_b<double, false>(a, shape, zero, grid, st); else launch_wilson_b<double, true>(a, shape, zero, grid, st); }
   else { if (a.nrhs == 1) launch_wilson_b<float, false>(a, shape, zero, grid, st); else launch_wilson_b<float, true>(a, shape, zero, grid, st); }
   QMG_LAUNCH_CHECK();
