@@ -144,3 +144,24 @@ def test_n15_pion_mass_matches_the_reference_table(tmp_path):
     assert ph.shape == (2 * 32 * 32,) and np.all(np.abs(ph) <= np.pi)
     Ux, Uy, g = eo_links(ph, 32)
     assert abs(qmg.u1_plaquette(qmg.DeviceArray.from_host(g), 32, 32)[0] - np_plaquette(Ux, Uy)[0]) < 1e-13
+
+
+@pytest.mark.parametrize("mass,m_pi_ref", [(0.1, 0.355891), (0.04, 0.202947)])
+def test_n20_staggered_pion_mass_matches_the_reference_table(mass, m_pi_ref):
+    """tests/n20_staggered_goldstone_u1_heatbath/critical_mass.txt:4,7: 32^2, beta = 6.0, m = 0.1 -> m_pi = 0.355891(41), m = 0.04 ->
+    0.202947(55).  The counterpart driver (device heatbath, one BiCGStab-6 staggered inversion per configuration, Goldstone correlator
+    through qmg_norm2sq_cv_timeslice), 400 configurations, cosh fit over t = 7..16 of the folded correlator.  The band (+-0.012) absorbs
+    statistics and the fit window and still separates the table's neighbouring masses (steps of 0.047 - 0.056)."""
+    from scipy.optimize import curve_fit
+    out = subprocess.run([os.path.join(DRIVERS, "n20_staggered_goldstone_u1_heatbath"), "32", str(mass), "6.0", "400", "100", "1000", "1337"], cwd=DRIVERS,
+                         env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "400 measurements, 0 unconverged" in out.stdout
+    body = out.stdout[out.stdout.index("[QMG-BEGIN-PION]"):out.stdout.index("[QMG-END-PION]")]
+    rows = re.findall(r"^(\d+) ([-\d.e+]+) \+/- ([-\d.e+]+)$", body, re.M)
+    t = np.array([int(r[0]) for r in rows], dtype=float)
+    c, dc = np.array([float(r[1]) for r in rows]), np.array([float(r[2]) for r in rows])
+    assert len(t) == 32 and np.all(c > 0)
+    sel = (t >= 7) & (t <= 16)
+    (amp, m_pi), cov = curve_fit(lambda tt, a, m: a * np.cosh(m * (tt - 16.0)), t[sel], c[sel], p0=(c[16], 0.3), sigma=dc[sel], absolute_sigma=True)
+    assert abs(m_pi - m_pi_ref) < 0.012, (mass, m_pi, np.sqrt(cov[1, 1]))
