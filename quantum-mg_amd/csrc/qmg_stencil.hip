@@ -775,6 +775,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
 // p+2 are in flight while piece p+1 computes.  The own-site vector in B layout IS the shift term's operand in C layout
 // (k-step s = 4 t + i holds row 16 t + 4 i + (lane>>4)); it is re-read from L2 in the epilogue.
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_lds_handoff() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -829,11 +830,18 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
     const long nb[5] = {site, opp + (long)y * a.hr + jp, opp + (long)yp * a.hr + j, opp + (long)y * a.hr + jm, opp + (long)ym * a.hr + j};
     const bool act[5] = {do_clover, (bool)(hop_mask & 1u), (bool)(hop_mask & 2u), (bool)(hop_mask & 4u), (bool)(hop_mask & 8u)};
 
-    v4d acc[NACC][RT];   // MODE 0: (re, im); MODE 1: (P, Q)
+    // complex<float> matrices AND vectors: the products run on the f32 matrix pipe (v_mfma_f32_16x16x4_f32, twice the f64
+    // rate on this part; same A / B / C lane maps as the f64 instruction), accumulating in fp32 like the rest of the fp32 path
+    constexpr bool F32M = M32 && V32;
+    typedef typename std::conditional<F32M, v4f32, v4d>::type accv;
+    accv acc[NACC][RT];   // MODE 0: (re, im); MODE 1: (P, Q)
 #pragma unroll
     for (int n = 0; n < NACC; n++)
 #pragma unroll
-      for (int t = 0; t < RT; t++) acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int t = 0; t < RT; t++) {
+        if constexpr (F32M) acc[n][t] = (v4f32){0.0f, 0.0f, 0.0f, 0.0f};
+        else acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      }
 
     constexpr int NGP = (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS per lane per piece (fp32-stored matrices)
     // staging registers for the matrix stream (a second set, two pieces of prefetch, was measured SLOWER: 8 rhs 2.88 -> 3.10
@@ -942,7 +950,24 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
           else B[set][0] = xv;
         }
         constexpr int qb = VL ? 0 : 1;            // VL: the fragment sits in slot 0; else slot q
-        if constexpr (MODE == 0) {
+        if constexpr (F32M && MODE == 0) {
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Af[t].x, (float)B[set][q * qb].x, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Af[t].x, (float)B[set][q * qb].y, acc[1][t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-(float)Af[t].y, (float)B[set][q * qb].y, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Af[t].y, (float)B[set][q * qb].x, acc[1][t], 0, 0, 0);
+          }
+        } else if constexpr (F32M) {
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Af[t].x, (float)B[set][q * qb], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Af[t].y, (float)B[set][q * qb], acc[1][t], 0, 0, 0);
+          }
+        } else if constexpr (MODE == 0) {
 #pragma unroll
           for (int t = 0; t < RT; t++) {
             acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t].x, B[set][q * qb].x, acc[0][t], 0, 0, 0);
@@ -987,12 +1012,12 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       for (int t = 0; t < RT; t++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int r = 16 * t + 4 * i + lq;
+          const int r = F32M ? 16 * t + 4 * lq + i : 16 * t + 4 * i + lq;   // C/D row of accumulator register i: the f32 instruction puts rows 4 lq .. 4 lq + 3 in a lane, the f64 one rows lq, lq + 4, ...
           cplx v;
-          if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
+          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[1][t][i]);
           else {   // partner lane (lr ^ 8) holds the other half of the packed columns
-            const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
-            v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[1][t][i], 8);
+            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[1][t][i]);
           }
           if (r < NC && (MODE != 1 || lr < 8)) xlds[kcol * XS + r] = v;
         }
@@ -1020,12 +1045,12 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       for (int t = 0; t < RT; t++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int r = 16 * t + 4 * i + lq;
+          const int r = F32M ? 16 * t + 4 * lq + i : 16 * t + 4 * i + lq;   // C/D row of accumulator register i: the f32 instruction puts rows 4 lq .. 4 lq + 3 in a lane, the f64 one rows lq, lq + 4, ...
           cplx v;
-          if (MODE == 0) v = cmake(acc[0][t][i], acc[1][t][i]);
+          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[1][t][i]);
           else {   // partner lane (lr ^ 8) holds the other half of the packed columns
-            const double pp = __shfl_xor(acc[0][t][i], 8), qp = __shfl_xor(acc[1][t][i], 8);
-            v = cmake(acc[0][t][i] - qp, pp + acc[1][t][i]);
+            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[1][t][i], 8);
+            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[1][t][i]);
           }
           if (r < NC && kval && (MODE != 1 || lr < 8)) {
             const long o = koff + site * NC + r;
