@@ -35,6 +35,18 @@ def test_two_rank_gloo_worker():
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
 
 
+def test_two_rank_slab_solve():
+    """ONE lattice over two gloo ranks: the host mirror of qmg_halo_exchange's message pattern and of the
+    distributed reductions drives a slab-decomposed BiCGStab solve whose assembled solution solves the global system of the
+    oracle (tests/slab_worker.py).  The HIP side of the same path is tests/test_gpu_slab.py."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "slab_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "slab worker ok" in out.stdout
+
+
 def test_rendezvous_times_out_instead_of_hanging():
     """A rank whose rank 0 never shows up gets an error after QMG_COMM_TIMEOUT_S, not a hang (the id-file
     hand-shake could block forever on a stale file)."""
