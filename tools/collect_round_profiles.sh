@@ -1,18 +1,33 @@
+# One GPU call that produces every round file under profiles/ (run on the GPU box: gpurun -- 'bash tools/collect_round_profiles.sh r02').
+# rocprofv3 gets the program itself after `--` (python3 file / a binary), counters in their own passes.
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $R
-rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > gpurun_out/prof_stats.log 2>&1
+O=gpurun_out
+rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_n13 $O/pmc_w_fetch $O/pmc_w_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > $O/prof_stats.log 2>&1
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > gpurun_out/prof_fetch.log 2>&1
-echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > gpurun_out/prof_write.log 2>&1
-echo write done
-python tools/summarize_profiles.py r02 > gpurun_out/summarize.log 2>&1
-cp profiles/r02_summary.md profiles/r02_pmc_traffic.json profiles/r02_kernel_stats.csv gpurun_out/ 
-echo summarized
-python tools/bench_r02.py > gpurun_out/r02_kernel_rooflines.json 2> gpurun_out/bench_r02.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > $O/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-also > $O/prof_write.log 2>&1
+echo pmc done
+python tools/summarize_profiles.py $TAG > $O/summarize.log 2>&1
+cp profiles/${TAG}_summary.md profiles/${TAG}_pmc_traffic.json profiles/${TAG}_kernel_stats.csv $O/
+python tools/bench_r02.py > $O/${TAG}_kernel_rooflines.json 2> $O/bench_r02.err
 echo kernels done
-python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err
+python tools/site_kernel_ab.py > $O/${TAG}_site_kernel_ab.txt 2>&1
+bash tools/pmc_wilson_direct.sh > $O/${TAG}_wilson_direct_pmc.txt 2>&1
+python tools/wilson_direct_bench.py >> $O/${TAG}_wilson_direct_pmc.txt 2>&1
+echo ab done
+QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_n13 -- quantum-mg_amd/drivers/n13_wilson_kcycle 2048 -0.07 6.0 2 24 tests/golden/l64t64b60_heatbath.dat 64 > $O/${TAG}_n13_kcycle_2048_nc24.log 2>&1
+python tools/solve_phase_profile.py $O/prof_n13 > $O/${TAG}_n13_solve_phase.json
+rm -rf $O/prof_n13
+echo n13 done
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 echo bench done
-tail -c 600 gpurun_out/r02_bench.json
+python -c "
+import json
+d=json.load(open('$O/${TAG}_bench.json'))
+print(d['value'], d['roofline']['frac'], d['roofline']['traffic'])
+print({k:(v.get('value') if isinstance(v,dict) else None) for k,v in d.items() if k.startswith('also_kcycle')})
+"
