@@ -317,6 +317,11 @@ int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, co
 int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, double wilson_coeff,
                          void* stream);
 int qmg_comm_set_distributed_reductions(int on);
+/* Test transport: `world` host threads of one process act as ranks on one GPU (device copies + host sums behind thread barriers),
+ * because one-GPU boxes cannot run two RCCL ranks.  Everything above the transport is the code the RCCL path runs. */
+int qmg_comm_emulate_begin(int world);
+int qmg_comm_emulate_attach(int rank);
+int qmg_comm_emulate_end(void);
 
 /* ---------------- the Wilson operator straight from the gauge links (csrc/qmg_wilson.hip, kernel W) ----------------
  * Same result as qmg_wilson_fill + qmg_stencil_apply (operators/wilson.h:153-209 + stencil_2d.h:912-936), without the stored

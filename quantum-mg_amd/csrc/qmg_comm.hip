@@ -31,6 +31,10 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
 #include <rccl/rccl.h>
 
 #include "qmg_common.h"
@@ -71,11 +75,55 @@ struct Rccl {
 };
 static Rccl g_rccl;
 
+// ---------------- ranks emulated by host threads of ONE process on ONE GPU (qmg_comm_emulate_*) ----------------
+// The pool's boxes have one GPU and RCCL refuses two ranks on one device, so more than one rank cannot run through RCCL here.
+// To still run the SLAB LOGIC -- which row goes to which neighbour, the distributed reductions, the lock-step decisions of a
+// solver on slabs -- with R > 1, R host threads can attach as ranks: the transport is then device copies between the
+// threads' arrays and host-side sums, fenced by thread barriers (slow, test-only); everything above the transport
+// (peer selection, buffer layout, call sequence) is the code the RCCL path runs.
+struct ThreadWorld {
+  int world = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<const void*> vec;             // [rank]: the vector whose rows the current exchange sends
+  std::vector<std::vector<double>> slot;    // [rank]: reduction operands
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long gen = generation;
+    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+};
+static ThreadWorld g_tw;
+static thread_local int t_rank = -1;        // >= 0: this host thread is an emulated rank
+static inline bool emulated() { return t_rank >= 0 && g_tw.world > 0; }
+static inline int my_world() { return emulated() ? g_tw.world : g_rccl.world; }
+static inline int my_rank() { return emulated() ? t_rank : g_rccl.rank; }
+
+// in-place sum / max over the emulated ranks of n doubles in HBM
+static int emulated_allreduce(double* buf_dev, int n, bool op_max, hipStream_t st) {
+  std::vector<double>& mine = g_tw.slot[t_rank];
+  mine.resize((size_t)n);
+  QMG_HIP_CHECK(hipMemcpyAsync(mine.data(), buf_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  QMG_HIP_CHECK(hipStreamSynchronize(st));
+  g_tw.barrier();
+  std::vector<double> total((size_t)n, 0.0);
+  for (int r = 0; r < g_tw.world; r++)      // rank order: every thread forms the same sum bit for bit
+    for (int i = 0; i < n; i++) total[i] = (r == 0) ? g_tw.slot[r][i] : (op_max ? (g_tw.slot[r][i] > total[i] ? g_tw.slot[r][i] : total[i]) : total[i] + g_tw.slot[r][i]);
+  g_tw.barrier();                           // everyone has read every slot
+  QMG_HIP_CHECK(hipMemcpyAsync(buf_dev, total.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+  QMG_HIP_CHECK(hipStreamSynchronize(st));   // `total` leaves scope
+  return QMG_SUCCESS;
+}
+
 // For the reduction entry points (qmg_blas.hip, qmg_batch.hip): with distributed reductions on and more than one rank
 // (or the forced 1-rank communicator of the tests), sum (or max) `n` doubles in HBM over the ranks, in place, on `st`.
-bool dist_reductions_on() { return g_rccl.dist_reduce && g_rccl.comm && (g_rccl.world > 1 || g_rccl.force); }
+bool dist_reductions_on() { return g_rccl.dist_reduce && (emulated() || (g_rccl.comm && (g_rccl.world > 1 || g_rccl.force))); }
 int dist_allreduce(double* buf_dev, int n, bool op_max, hipStream_t st) {
   if (!dist_reductions_on() || n == 0) return QMG_SUCCESS;
+  if (emulated()) return emulated_allreduce(buf_dev, n, op_max, st);
   if (g_rccl.all_reduce(buf_dev, buf_dev, (size_t)n, ncclDouble, op_max ? ncclMax : ncclSum, g_rccl.comm, st) != ncclSuccess) return QMG_ERR_HIP;
   return QMG_SUCCESS;
 }
@@ -189,6 +237,7 @@ int qmg_comm_get_unique_id(void* id128) {
 
 // Collective over all ranks; the device must already be selected with qmg_init(local_rank).
 int qmg_comm_init(const void* id128, int world, int rank) {
+  if (emulated()) return (world == g_tw.world && rank == t_rank) ? QMG_SUCCESS : QMG_ERR_INVALID;   // thread ranks: nothing to set up
   if (!id128 || world < 1 || rank < 0 || rank >= world) return QMG_ERR_INVALID;
   g_rccl.world = world;
   g_rccl.rank = rank;
@@ -211,6 +260,7 @@ int qmg_comm_rendezvous(void* blob128, int world, int rank) {
 
 // qmg_comm_init with the id obtained through the launcher's rendezvous (see the header of this file).
 int qmg_comm_init_env(int world, int rank) {
+  if (emulated()) return (world == g_tw.world && rank == t_rank) ? QMG_SUCCESS : QMG_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world) return QMG_ERR_INVALID;
   const bool force = getenv("QMG_COMM_FORCE_RCCL") != nullptr;
   ncclUniqueId id;
@@ -228,14 +278,15 @@ int qmg_comm_init_env(int world, int rank) {
 }
 
 int qmg_comm_world(int* world, int* rank) {
-  if (world) *world = g_rccl.world;
-  if (rank) *rank = g_rccl.rank;
+  if (world) *world = my_world();
+  if (rank) *rank = my_rank();
   return QMG_SUCCESS;
 }
 
 // In-place sum over ranks of n doubles in HBM, asynchronous on `stream`. world == 1: no-op.
 int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream) {
   if (!buf_dev && n) return QMG_ERR_INVALID;
+  if (emulated()) return n ? emulated_allreduce(buf_dev, (int)n, false, as_stream(stream)) : QMG_SUCCESS;
   if ((g_rccl.world == 1 && !g_rccl.force) || n == 0) return QMG_SUCCESS;
   if (!g_rccl.comm) return QMG_ERR_INVALID;
   if (g_rccl.all_reduce(buf_dev, buf_dev, n, ncclDouble, ncclSum, g_rccl.comm, as_stream(stream)) != ncclSuccess) return QMG_ERR_HIP;
@@ -247,6 +298,15 @@ int qmg_allreduce_sum_f64(double* buf_dev, size_t n, void* stream) {
 int qmg_comm_all_ok(int ok, int* all_ok) {
   if (!all_ok) return QMG_ERR_INVALID;
   *all_ok = ok ? 1 : 0;
+  if (emulated()) {
+    g_tw.slot[t_rank].assign(1, ok ? 0.0 : 1.0);
+    g_tw.barrier();
+    double bad_total = 0.0;
+    for (int r = 0; r < g_tw.world; r++) bad_total += g_tw.slot[r][0];
+    g_tw.barrier();
+    *all_ok = (bad_total == 0.0) ? 1 : 0;
+    return QMG_SUCCESS;
+  }
   if (g_rccl.world == 1 && !g_rccl.force) return QMG_SUCCESS;
   if (!g_rccl.comm) return QMG_ERR_INVALID;
   static double* flag = nullptr;   // one rank = one device = one buffer
@@ -264,8 +324,8 @@ int qmg_comm_all_ok(int ok, int* all_ok) {
 // batch reductions) returns the sum (max for norminf) over all ranks -- the vectors are slabs of one lattice.  Off (the
 // default): reductions are local, as for ranks that hold different right-hand sides.  Needs an initialised communicator.
 int qmg_comm_set_distributed_reductions(int on) {
-  if (on && !g_rccl.comm && (g_rccl.world > 1 || g_rccl.force)) return QMG_ERR_INVALID;
-  g_rccl.dist_reduce = on != 0;
+  if (on && !emulated() && !g_rccl.comm && (g_rccl.world > 1 || g_rccl.force)) return QMG_ERR_INVALID;
+  g_rccl.dist_reduce = on != 0;   // (emulated ranks all write the same value)
   return QMG_SUCCESS;
 }
 
@@ -284,8 +344,26 @@ int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* 
   const size_t half = row * (size_t)Ly;
   if (nrhs > 1 && (vec_stride < 2 * half || halo_stride < 2 * row)) return QMG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
-  const bool rccl = g_rccl.comm && (g_rccl.world > 1 || g_rccl.force);
-  const int up = (g_rccl.rank + 1) % g_rccl.world, down = (g_rccl.rank + g_rccl.world - 1) % g_rccl.world;
+  const bool rccl = !emulated() && g_rccl.comm && (g_rccl.world > 1 || g_rccl.force);
+  const int up = (my_rank() + 1) % my_world(), down = (my_rank() + my_world() - 1) % my_world();
+  if (emulated()) {   // post my vector, fetch the neighbours' rows with device copies (same layout on every rank)
+    QMG_HIP_CHECK(hipStreamSynchronize(st));          // my rows are final
+    g_tw.vec[t_rank] = vec;
+    g_tw.barrier();
+    int erc = QMG_SUCCESS;
+    for (int k = 0; k < nrhs && erc == QMG_SUCCESS; k++)
+      for (int q = 0; q < 2; q++) {
+        const char* vdn = (const char*)g_tw.vec[down] + (size_t)k * vec_stride * esz;   // down's LAST row is my row -1
+        const char* vup = (const char*)g_tw.vec[up] + (size_t)k * vec_stride * esz;     // up's FIRST row is my row Ly
+        char* lo = (char*)halo_lo + ((size_t)k * halo_stride + (size_t)q * row) * esz;
+        char* hi = (char*)halo_hi + ((size_t)k * halo_stride + (size_t)q * row) * esz;
+        if (hipMemcpyAsync(lo, vdn + ((size_t)q * half + (size_t)(Ly - 1) * row) * esz, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) erc = QMG_ERR_HIP;
+        if (hipMemcpyAsync(hi, vup + ((size_t)q * half) * esz, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) erc = QMG_ERR_HIP;
+      }
+    QMG_HIP_CHECK(hipStreamSynchronize(st));          // my copies are done ...
+    g_tw.barrier();                                    // ... and so are everybody's: the vectors may change again
+    return erc;
+  }
   const ncclDataType_t unit = ncclChar;
   if (rccl && g_rccl.group_start() != ncclSuccess) return QMG_ERR_HIP;
   int rc = QMG_SUCCESS;
@@ -313,7 +391,31 @@ int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* 
   return rc;
 }
 
+// Ranks emulated by host threads (see ThreadWorld above).  qmg_comm_emulate_begin(world) once, from the thread that then starts
+// `world` threads; each of those calls qmg_comm_emulate_attach(rank) first and qmg_init(device) as usual; qmg_comm_emulate_end()
+// after they have joined.  While attached, qmg_comm_world / qmg_halo_exchange / qmg_allreduce_sum_f64 / qmg_comm_all_ok and the
+// distributed reductions see `world` ranks.
+int qmg_comm_emulate_begin(int world) {
+  if (world < 1 || g_tw.world != 0) return QMG_ERR_INVALID;
+  g_tw.world = world; g_tw.arrived = 0; g_tw.generation = 0;
+  g_tw.vec.assign((size_t)world, nullptr);
+  g_tw.slot.assign((size_t)world, std::vector<double>());
+  return QMG_SUCCESS;
+}
+int qmg_comm_emulate_attach(int rank) {
+  if (g_tw.world == 0 || rank < 0 || rank >= g_tw.world) return QMG_ERR_INVALID;
+  t_rank = rank;
+  return QMG_SUCCESS;
+}
+int qmg_comm_emulate_end(void) {
+  g_tw.world = 0; g_tw.vec.clear(); g_tw.slot.clear();
+  t_rank = -1;
+  g_rccl.dist_reduce = false;
+  return QMG_SUCCESS;
+}
+
 int qmg_comm_finalize(void) {
+  if (emulated()) return QMG_SUCCESS;   // the emulating process ends with qmg_comm_emulate_end
   if (g_rccl.comm) { g_rccl.comm_destroy(g_rccl.comm); g_rccl.comm = nullptr; }
   g_rccl.world = 1; g_rccl.rank = 0; g_rccl.force = false; g_rccl.dist_reduce = false;
   return QMG_SUCCESS;

@@ -15,7 +15,11 @@
 #include <cmath>
 #include <iomanip>
 #include <iostream>
+#include <mutex>
+#include <sstream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../include/qmg/qmg.hpp"
 #include "../include/qmg/slab.hpp"
@@ -23,12 +27,12 @@
 using namespace std;
 
 static double now() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+static std::mutex g_print;
+static void say(const std::ostringstream& line) { std::lock_guard<std::mutex> lk(g_print); std::cout << line.str() << std::flush; }
 
-int main(int argc, char** argv) {
-  if (argc < 4) { cout << "usage: ./slab_wilson_solve L mass beta [n_therm seed tol verify overlap]\n"; return -1; }
-  const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
-  const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
-  if (!qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
+// one rank: a process of the launcher, or -- QMG_COMM_EMULATE=R -- one of R host threads of this process (test transport)
+static int run(int rank, int world, int device, int argc, char** argv) {
+  if (!qmg::ok(qmg_init(device), "qmg_init")) return 2;
   if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env")) return 2;
   const int L = stoi(argv[1]);
   const double mass = stod(argv[2]), beta = stod(argv[3]);
@@ -38,16 +42,15 @@ int main(int argc, char** argv) {
   const bool verify = (argc > 7) ? stoi(argv[7]) != 0 : true;
   const bool overlap = (argc > 8) ? stoi(argv[8]) != 0 : true;
   const bool root = rank == 0;
-  cout << setprecision(15);
 
   qmg::SlabGeometry geo(L, L, world, rank);
   int all = 0;
   if (!qmg::ok(qmg_comm_all_ok(geo.valid ? 1 : 0, &all), "qmg_comm_all_ok") || !all) {
-    if (root) cout << "[QMG-SLAB]: " << L << " rows do not split into " << world << " slabs of an even number of rows\n";
+    if (root) { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: " << L << " rows do not split into " << world << " slabs of an even number of rows\n"; say(o_); }
     qmg_comm_finalize();
     return 3;
   }
-  if (root) cout << "[QMG-SLAB]: " << L << " x " << L << " Wilson, mass " << mass << ", beta " << beta << ": " << world << " slab(s) of " << geo.Ly_local << " rows\n";
+  if (root) { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: " << L << " x " << L << " Wilson, mass " << mass << ", beta " << beta << ": " << world << " slab(s) of " << geo.Ly_local << " rows\n"; say(o_); }
 
   // ---- the same gauge field on every rank
   Lattice2D* lat_gauge = new Lattice2D(L, L, 1);
@@ -59,7 +62,7 @@ int main(int argc, char** argv) {
   heatbath_noncompact_update(phases, lat_gauge, beta, n_therm, generator);
   polar_vector(phases, gauge, ng);
   const double plaq = std::real(get_plaquette_u1(gauge, lat_gauge));
-  if (root) cout << "[QMG-SLAB]: plaquette after " << n_therm << " heatbath sweeps " << plaq << "\n";
+  if (root) { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: plaquette after " << n_therm << " heatbath sweeps " << plaq << "\n"; say(o_); }
 
   // ---- this rank's rows of the operator and of the source
   qmg::SlabWilson2D* op = new qmg::SlabWilson2D(geo, mass, gauge);
@@ -82,8 +85,8 @@ int main(int argc, char** argv) {
       op->apply_M(r, b);
       const double d2 = diffnorm2sq(r, x, nl), n2 = norm2sq(x, nl);   // local: distributed reductions are still off
       ok_here = (d2 <= 1e-26 * n2) ? 1 : 0;
-      cout << "[QMG-SLAB]: rank " << rank << " rows [" << geo.y0 << ", " << geo.y0 + geo.Ly_local << "): slab apply vs single-domain apply, rel diff " << sqrt(d2 / n2)
-           << (ok_here ? " (ok)" : " (MISMATCH)") << "\n";
+      { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: rank " << rank << " rows [" << geo.y0 << ", " << geo.y0 + geo.Ly_local << "): slab apply vs single-domain apply, rel diff " << sqrt(d2 / n2)
+           << (ok_here ? " (ok)" : " (MISMATCH)") << "\n"; say(o_); }
       deallocate_vector(&yg);
       delete wilson; delete lat;
     }
@@ -105,7 +108,7 @@ int main(int argc, char** argv) {
     ms_apply[mode] = (now() - t0) / reps * 1e3;
   }
   op->overlap = overlap;
-  if (root) cout << "[QMG-SLAB]: apply_M on a slab: " << ms_apply[0] << " ms with the exchange overlapped, " << ms_apply[1] << " ms serialised\n";
+  if (root) { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: apply_M on a slab: " << ms_apply[0] << " ms with the exchange overlapped, " << ms_apply[1] << " ms serialised\n"; say(o_); }
 
   // ---- the solve
   zero_vector(x, nl);
@@ -120,8 +123,8 @@ int main(int argc, char** argv) {
   const double relres = sqrt(diffnorm2sq(b, r, nl)) / bnorm;
   const double xnorm2 = norm2sq(x, nl);
   if (root)
-    cout << "[QMG-SLAB]: BiCGStab-6 " << (info.success ? "converged" : "FAILED") << " in " << info.iter << " iterations, " << secs << " s, " << op->applies - applies0 - 1
-         << " applies, true relative residual " << relres << ", |b| " << bnorm << ", |x|^2 " << xnorm2 << ", world " << world << "\n";
+    { std::ostringstream o_; o_ << setprecision(15) << "[QMG-SLAB]: BiCGStab-6 " << (info.success ? "converged" : "FAILED") << " in " << info.iter << " iterations, " << secs << " s, " << op->applies - applies0 - 1
+         << " applies, true relative residual " << relres << ", |b| " << bnorm << ", |x|^2 " << xnorm2 << ", world " << world << "\n"; say(o_); }
   const int good = info.success && relres < 10 * tol;
   qmg_comm_all_ok(good, &all);
 
@@ -131,4 +134,32 @@ int main(int argc, char** argv) {
   qmg::VecPool::release_all();
   qmg_comm_finalize();
   return all ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) { std::cout << "usage: ./slab_wilson_solve L mass beta [n_therm seed tol verify overlap]\n"; return -1; }
+  const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
+  if (emulate > 0) {   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
+    std::vector<int> rc(emulate, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < emulate; r++)
+      th.emplace_back([&, r] {
+        qmg_comm_emulate_attach(r);
+        void* st = 0;
+        qmg_stream_create(&st);              // one stream per emulated rank
+        qmg::current_stream() = st;
+        rc[r] = run(r, emulate, 0, argc, argv);
+        qmg_stream_sync(st);
+        qmg::current_stream() = 0;
+        qmg_stream_destroy(st);
+      });
+    for (auto& t : th) t.join();
+    qmg_comm_emulate_end();
+    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
+    return 0;
+  }
+  const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+  const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
+  return run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, argc, argv);
 }

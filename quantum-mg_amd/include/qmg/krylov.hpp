@@ -29,7 +29,8 @@ namespace qmg {
 struct VecPool {
   std::vector<complex<double>*> v;
   size_t n;
-  static std::map<size_t, std::vector<complex<double>*>>& cache() { static std::map<size_t, std::vector<complex<double>*>> c; return c; }
+  // per host thread (a thread = one stream = one rank when ranks are emulated by threads: qmg_comm_emulate_*)
+  static std::map<size_t, std::vector<complex<double>*>>& cache() { static thread_local std::map<size_t, std::vector<complex<double>*>> c; return c; }
   explicit VecPool(size_t n_) : n(n_) {}
   complex<double>* get() {
     std::vector<complex<double>*>& fl = cache()[n];
@@ -96,7 +97,7 @@ inline std::vector<complex<double>> gcr_direction_weights(const std::vector<comp
 // entry (nested preconditioner solves never see it), skips that apply and its two vector passes, and does not count it
 // in ops_count.  Results are bit-identical to the unhinted path.
 namespace qmg {
-inline bool& zero_guess_flag() { static bool f = false; return f; }
+inline bool& zero_guess_flag() { static thread_local bool f = false; return f; }
 inline bool take_zero_guess() { bool f = zero_guess_flag(); zero_guess_flag() = false; return f; }
 struct ZeroGuess { ZeroGuess() { zero_guess_flag() = true; } ~ZeroGuess() { zero_guess_flag() = false; } };
 }  // namespace qmg

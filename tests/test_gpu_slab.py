@@ -208,3 +208,34 @@ def test_slab_solve_driver_on_one_rank(forced_rccl):
     # a world the rows do not divide into is refused by every rank together
     bad = subprocess.run([os.path.join(drivers, "slab_wilson_solve"), "6", "0.05", "6.0", "1"], cwd=drivers, env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=60)
     assert bad.returncode == 0 or "do not split" in bad.stdout      # 6 rows on one rank are fine; the refusal needs world > 1 (not reachable on one GPU)
+
+
+@pytest.mark.parametrize("L,R", [(64, 2), (64, 4), (128, 8)])
+def test_slab_solve_with_ranks_emulated_by_threads(L, R):
+    """More than one rank on a one-GPU box: R host threads attach as ranks (qmg_comm_emulate_*, csrc/qmg_comm.hip), the transport
+    becomes device copies + host sums behind thread barriers, and everything above it is the code the RCCL path runs -- peer
+    selection and halo layout of qmg_halo_exchange, the library's distributed reductions, the slab operator, BiCGStab-6 in lock
+    step.  Every rank's slab apply (with REAL neighbours) must equal its rows of the single-domain apply bit for bit, and the
+    solve must agree with the one-rank solve: same |b|, the solution's norm to 1e-9, iteration counts within 2 (the
+    reductions sum the slabs' partial results, so the rounding -- not the arithmetic -- differs)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(drivers, "slab_wilson_solve")
+    args = [exe, str(L), "0.05", "6.0", "100", "7"]
+    pat = r"BiCGStab-6 converged in (\d+) iterations, .* true relative residual ([\d.e+-]+), \|b\| ([\d.e+-]+), \|x\|\^2 ([\d.e+-]+), world (\d+)"
+    one = subprocess.run(args, cwd=drivers, env=dict(os.environ, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    many = subprocess.run(args, cwd=drivers, env=dict(os.environ, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and many.returncode == 0, many.stdout[-2500:] + many.stderr[-1500:]
+    checks = re.findall(r"rank (\d+) rows \[(\d+), (\d+)\): slab apply vs single-domain apply, rel diff ([\d.e+-]+) \((ok|MISMATCH)\)", many.stdout)
+    assert sorted(int(c[0]) for c in checks) == list(range(R)) and all(c[4] == "ok" and float(c[3]) == 0.0 for c in checks), checks
+    assert sorted((int(c[1]), int(c[2])) for c in checks) == [(r * L // R, (r + 1) * L // R) for r in range(R)]
+    m1, mR = re.search(pat, one.stdout), re.search(pat, many.stdout)
+    assert m1 and mR, many.stdout[-1500:]
+    assert int(mR.group(5)) == R and float(mR.group(2)) < 1e-9
+    assert m1.group(3) == mR.group(3) or abs(float(m1.group(3)) - float(mR.group(3))) < 1e-12 * float(m1.group(3))      # |b|: a sum in another order
+    assert abs(float(m1.group(4)) - float(mR.group(4))) < 1e-9 * float(m1.group(4))
+    assert abs(int(m1.group(1)) - int(mR.group(1))) <= 2
