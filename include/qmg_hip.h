@@ -317,6 +317,11 @@ int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, co
 int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, double wilson_coeff,
                          void* stream);
 int qmg_comm_set_distributed_reductions(int on);
+/* setup on slabs: the Galerkin build with the null vectors' halo rows, and a Gaussian vector that equals the slab's rows of the
+ * single-domain qmg_gaussian vector with the same seed (so a decomposed run draws the single-domain run's vectors) */
+int qmg_coarse_build_slab(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs, const void* restrict_vecs, int cLx, int cLy, int cnc,
+                          const void* P_halo_lo, const void* P_halo_hi, size_t halo_stride, void* stream);
+int qmg_gaussian_slab(void* x, int Lx, int Ly_global, int y0, int Ly_local, int nc, unsigned long long seed, void* stream);
 /* Test transport: `world` host threads of one process act as ranks on one GPU (device copies + host sums behind thread barriers),
  * because one-GPU boxes cannot run two RCCL ranks.  Everything above the transport is the code the RCCL path runs. */
 int qmg_comm_emulate_begin(int world);

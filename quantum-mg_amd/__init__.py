@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_stencil_apply_h16",
-    "qmg_wilson_apply_direct", "qmg_halo_exchange", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
+    "qmg_wilson_apply_direct", "qmg_halo_exchange", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -337,6 +337,15 @@ def block_bi_orthonormalize(pvecs, rvecs, nvec, fdims, cLx, cLy, block_L=None, b
 
 def coarse_build(cclover, chopping, fdesc, nullvecs, cdims, restrict_vecs=None):
     check(lib().qmg_coarse_build(_vp(cclover), _vp(chopping), C.byref(fdesc), _vp(nullvecs), _vp(restrict_vecs), *cdims, None), "qmg_coarse_build")
+
+
+def coarse_build_slab(cclover, chopping, fdesc, nullvecs, cdims, halo_lo, halo_hi, halo_stride, restrict_vecs=None):
+    check(lib().qmg_coarse_build_slab(_vp(cclover), _vp(chopping), C.byref(fdesc), _vp(nullvecs), _vp(restrict_vecs), *cdims, _vp(halo_lo), _vp(halo_hi),
+                                      C.c_size_t(halo_stride), None), "qmg_coarse_build_slab")
+
+
+def gaussian_slab(x, Lx, Ly_global, y0, Ly_local, nc, seed):
+    check(lib().qmg_gaussian_slab(_vp(x), Lx, Ly_global, y0, Ly_local, nc, C.c_ulonglong(seed), None), "qmg_gaussian_slab")
 
 
 # ---------------- lock-step batches (qmg_batch.hip) ----------------

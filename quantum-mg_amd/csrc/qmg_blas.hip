@@ -81,6 +81,24 @@ __global__ __launch_bounds__(BLOCK) void k_gaussian(cplx* __restrict__ x, long n
   }
 }
 
+// the same numbers for the rows [y0, y0 + Ly_l) of a (cv) vector over the lattice Lx x Ly_g: element i of the slab takes the value
+// the element at its GLOBAL position would get from k_gaussian -- a slab-decomposed run draws the single-domain run's vectors
+__global__ __launch_bounds__(BLOCK) void k_gaussian_slab(cplx* __restrict__ x, int hr, int Ly_g, int y0, int Ly_l, int nc, unsigned long long seed) {
+  const long row = (long)hr * nc, n = 2 * row * Ly_l;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long q = i / (row * Ly_l), rem = i - q * row * Ly_l;          // parity, offset inside the slab's half
+    const unsigned long long gi = (unsigned long long)((q * Ly_g + y0) * row + rem);
+    const unsigned long long h1 = splitmix64(seed * 0xD1342543DE82EF95ull + 2ull * gi);
+    const unsigned long long h2 = splitmix64(h1 + 2ull * gi + 1ull);
+    const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);   // (0,1]
+    const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    x[i] = cmake(rad * cs, rad * sn);
+  }
+}
+
 // ---------------- reductions ----------------
 enum RedOp { RED_NORM2, RED_DOT, RED_DIFFNORM2, RED_NORMINF };
 
@@ -353,6 +371,13 @@ int qmg_gaussian(void* x, size_t n, unsigned long long seed, void* s) {
   if (!x && n) return QMG_ERR_INVALID;
   if (n == 0) return QMG_SUCCESS;
   k_gaussian<<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)x, (long)n, seed);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+int qmg_gaussian_slab(void* x, int Lx, int Ly_global, int y0, int Ly_local, int nc, unsigned long long seed, void* s) {
+  if (!x || !valid_lattice(Lx, Ly_global) || !valid_lattice(Lx, Ly_local) || nc < 1 || y0 < 0 || y0 + Ly_local > Ly_global) return QMG_ERR_INVALID;
+  k_gaussian_slab<<<grid_1d((size_t)Lx * Ly_local * nc), BLOCK, 0, as_stream(s)>>>((cplx*)x, Lx / 2, Ly_global, y0, Ly_local, nc, seed);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

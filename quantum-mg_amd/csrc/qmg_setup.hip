@@ -137,8 +137,11 @@ __global__ __launch_bounds__(BLOCK) void k_block_ortho(cplx* __restrict__ nullv,
 // goes to the coarse clover (coarse.h:222-224, 250-252), one that leaves it to the coarse hopping of that direction,
 // stored at the OUTPUT site X as in the fine layout.  The identity shift is NOT part of the build (coarse.h:131).
 constexpr int GAL_MAXOUT = 4;   // output entries per thread: nc_c^2 <= 4 * 256, i.e. nc_c <= 32
+// y-slab of a larger lattice: the prolongator's rows -1 / fLy (needed by the -y / +y hops that leave the slab) come from
+// P_lo / P_hi ([null vector][parity][fhr][nf], halo_stride elements between vectors; qmg_halo_exchange of the null vectors).
 __global__ __launch_bounds__(BLOCK) void k_galerkin(cplx* __restrict__ cclover, cplx* __restrict__ chopping, const cplx* __restrict__ fclover,
-                                                    const cplx* __restrict__ fhopping, const cplx* __restrict__ P, const cplx* __restrict__ R, const SetupGeom g) {
+                                                    const cplx* __restrict__ fhopping, const cplx* __restrict__ P, const cplx* __restrict__ R, const SetupGeom g,
+                                                    const cplx* __restrict__ P_lo, const cplx* __restrict__ P_hi, long halo_stride) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int nf = g.fnc, nc = g.cnc;
   cplx* Vx = reinterpret_cast<cplx*>(smem_raw);   // [nf][nc]   R(x)[r][a]
@@ -172,12 +175,19 @@ __global__ __launch_bounds__(BLOCK) void k_galerkin(cplx* __restrict__ cclover, 
           if (p == 2) ny = (y + 1 == g.fLy) ? 0 : y + 1;
           if (p == 3) nx = (x == 0) ? fLx - 1 : x - 1;
           if (p == 4) ny = (y == 0) ? g.fLy - 1 : y - 1;
-          const bool inside = (nx / g.bx == cx) && (ny / g.by == cy);
-          const int npar = (nx + ny) & 1;
-          const long nsite = (long)(ny + npar * g.fLy) * g.fhr + (nx >> 1);
+          // a hop that leaves the slab reads the prolongator from the halo rows (and is a coarse HOP, never clover)
+          const cplx* Pn = P;
+          long pstride = g.fsize;
+          bool off_slab = false;
+          if (p == 2 && P_hi && y + 1 == g.fLy) { Pn = P_hi; off_slab = true; }
+          if (p == 4 && P_lo && y == 0) { Pn = P_lo; off_slab = true; }
+          const bool inside = !off_slab && (nx / g.bx == cx) && (ny / g.by == cy);
+          const int npar = (nx + (off_slab ? (p == 2 ? y + 1 : y - 1) : ny)) & 1;   // colour of the neighbour on the GLOBAL lattice
+          long nsite = (long)(ny + npar * g.fLy) * g.fhr + (nx >> 1);
+          if (off_slab) { nsite = (long)npar * g.fhr + (nx >> 1); pstride = halo_stride; }
           const cplx* M = (p == 0) ? fclover + site * nf * nf : fhopping + (long)(p - 1) * fvol_cm + site * nf * nf;
           __syncthreads();   // previous piece's products have read Vn, Mp, T
-          for (int k = tid; k < nf * nc; k += BLOCK) { const int b = k / nf, c = k - b * nf; Vn[c * nc + b] = P[(long)b * g.fsize + nsite * nf + c]; }
+          for (int k = tid; k < nf * nc; k += BLOCK) { const int b = k / nf, c = k - b * nf; Vn[c * nc + b] = Pn[(long)b * pstride + nsite * nf + c]; }
           for (int k = tid; k < nf * nf; k += BLOCK) Mp[k] = M[k];
           __syncthreads();
           for (int k = tid; k < nf * nc; k += BLOCK) {   // T[r][b] = sum_c M[r][c] P(nb)[c][b]
@@ -271,19 +281,30 @@ int qmg_block_orthonormalize(void* nullvecs, int nvec, int fLx, int fLy, int fnc
 // colour counts beyond 32 or fine blocks beyond LDS.  Asynchronous on `stream`, no allocation.
 int qmg_coarse_build(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs, const void* restrict_vecs, int cLx, int cLy, int cnc,
                      void* stream) {
+  return qmg_coarse_build_slab(cclover, chopping, fine, nullvecs, restrict_vecs, cLx, cLy, cnc, nullptr, nullptr, 0, stream);
+}
+
+// The same on a y-slab: P_halo_lo / P_halo_hi = the null vectors' rows -1 / fLy from the neighbouring ranks (qmg_halo_exchange with
+// nrhs = cnc, vec_stride = the fine size_cv), halo_stride elements between vectors; NULL = periodic in y (the whole lattice).
+int qmg_coarse_build_slab(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs, const void* restrict_vecs, int cLx, int cLy, int cnc,
+                          const void* P_halo_lo, const void* P_halo_hi, size_t halo_stride, void* stream) {
   if (!cclover || !chopping || !fine || !nullvecs) return QMG_ERR_INVALID;
+  if ((P_halo_lo == nullptr) != (P_halo_hi == nullptr)) return QMG_ERR_INVALID;
   SetupGeom g;
   int rc = make_sgeom(&g, fine->Lx, fine->Ly, fine->nc, cLx, cLy, cnc);
   if (rc) return rc;
   const int nf = fine->nc;
   const size_t smem = sizeof(cplx) * ((size_t)3 * nf * cnc + (size_t)nf * nf);
-  if (!g_setup_fused || cnc * cnc > GAL_MAXOUT * BLOCK || smem > 150 * 1024)
+  if (!g_setup_fused || cnc * cnc > GAL_MAXOUT * BLOCK || smem > 150 * 1024) {
+    if (P_halo_lo) return QMG_ERR_UNSUPPORTED;   // the full-lattice probe passes have no halo step
     return coarse_build_probes(cclover, chopping, fine, nullvecs, restrict_vecs, cLx, cLy, cnc, stream);
+  }
   long nwg = (long)cLx * cLy;
   if (nwg > 262144) nwg = 262144;
   if (smem > 64 * 1024) QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_galerkin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   k_galerkin<<<(unsigned)nwg, BLOCK, smem, as_stream(stream)>>>((cplx*)cclover, (cplx*)chopping, (const cplx*)fine->clover, (const cplx*)fine->hopping,
-                                                               (const cplx*)nullvecs, (const cplx*)(restrict_vecs ? restrict_vecs : nullvecs), g);
+                                                               (const cplx*)nullvecs, (const cplx*)(restrict_vecs ? restrict_vecs : nullvecs), g,
+                                                               (const cplx*)P_halo_lo, (const cplx*)P_halo_hi, (long)halo_stride);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

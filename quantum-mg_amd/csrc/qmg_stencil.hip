@@ -50,6 +50,11 @@ struct StencilArgs {
   int use_idx;       // 0: column k is right-hand side k
   int mat32;         // 1: clover / hopping point to complex<float> arrays (kernels B and C: qmg_stencil_apply_mat32, qmg_stencil_apply_t)
   int vec32;         // 1: lhs / rhs are complex<float> (qmg_stencil_apply_t with QMG_C32: matrices AND vectors fp32)
+  // y-slab of a larger lattice (kernel B only; qmg_stencil_apply_slab): rows -1 / Ly of the right-hand side come from these
+  // buffers ([system][parity][hr][nc] complex, halo_stride elements between systems) instead of the periodic wrap
+  const void* halo_lo;
+  const void* halo_hi;
+  long halo_stride;
 #ifdef QMG_DIAGNOSTICS
   int ablate;        // tools-only build (make DIAG=1; tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 #endif
@@ -521,9 +526,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
           else if (piece == 1) nbsite = opp + (long)yp * a.hr + j;
           else if (piece == 2) { int jm = j + s - 1; if (jm < 0) jm = a.hr - 1; nbsite = opp + (long)y * a.hr + jm; }
           else nbsite = opp + (long)ym * a.hr + j;
+          // a slab's rows -1 / Ly: the opposite-parity row of the halo buffer (row-uniform choice)
+          const bool hi = piece == 1 && a.halo_hi && y + 1 == a.Ly, lo = piece == 3 && a.halo_lo && y == 0;
+          const long hsite = (long)(1 - p) * a.hr + j;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+            if (kk < nk) {
+              const int ks = a.use_idx ? (int)a.ridx[k0 + kk] : k0 + kk;
+              if (hi) xstage[kk] = ldv<V32>(a.halo_hi, (long)ks * a.halo_stride + hsite * nc + cc);
+              else if (lo) xstage[kk] = ldv<V32>(a.halo_lo, (long)ks * a.halo_stride + hsite * nc + cc);
+              else xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+            }
         }
       };
       if (oi < 5) { cur = order[oi]; prefetch(cur); }
@@ -1131,7 +1144,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0);
+                              const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0, const SlabHalo* slab = nullptr);
 
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
@@ -1186,7 +1199,7 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32, int vec32) {
+                              const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -1200,8 +1213,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.vec32 = vec32;
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
-  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5))) {
-    const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !(g_stencil_site & 4), nullptr);
+  if (slab && (mat32 != vec32 || (mat32 && nc != 2))) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2, either precision) or kernel B (fp64)
+  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
+    const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !slab && !(g_stencil_site & 4), slab);
     if (rc != SITE_DECLINED) return rc;
   }
   a.hr = d->Lx / 2;
@@ -1213,6 +1227,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.vec_stride = (long)vec_stride;
   a.use_idx = ridx ? 1 : 0;
   a.mat32 = mat32;
+  a.halo_lo = slab ? slab->lo : nullptr;
+  a.halo_hi = slab ? slab->hi : nullptr;
+  a.halo_stride = slab ? slab->stride : 0;
   for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
 #ifdef QMG_DIAGNOSTICS
   a.ablate = g_stencil_ablate;
@@ -1235,7 +1252,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   // kernel, profiles/r02_kernel_rooflines.json: half the bytes per site leave the paired kernel's longer dependent chain
   // exposed), so the paired kernel serves fp64 only unless "stencil_pair" asks for it explicitly (>= 8)
   const bool use_pair = vec32 ? (g_stencil_pair >= 8) : (g_stencil_pair > 0);
-  if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && use_pair && lhs != rhs) {
+  if ((nc == 1 || nc == 2 || nc == 4) && a.par_count == 2 && use_pair && lhs != rhs && !slab) {
     const int E = (vec32 && nc % 2 == 0) ? nc * nc / 2 : nc * nc;   // lanes per site (KA<T, NC>::E)
     const int rows = ((g_stencil_pair & 7) >= 4 && d->Ly % 4 == 0) ? 4 : ((g_stencil_pair & 7) >= 2 && d->Ly % 2 == 0) ? 2 : 1;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
@@ -1260,7 +1277,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     return QMG_SUCCESS;
   }
 
-  if (nc == 1 || nc == 2 || nc == 4) {
+  if ((nc == 1 || nc == 2 || nc == 4) && !slab) {
     const int E = (vec32 && nc % 2 == 0) ? nc * nc / 2 : nc * nc;
     const unsigned gx = (unsigned)((a.hr + BLOCK / E - 1) / (BLOCK / E));
     dim3 grid(gx, gy), block(BLOCK);
@@ -1286,7 +1303,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   // kernel B's shared tile wins (nc = 8, 1024^2, 3 rhs: 1.06 vs 1.39 ms) and it serves every other nc
   // (nc <= 16: kernel B with one 4-accumulator pass still wins at exactly 4 systems -- nc = 8, 1024^2: 1.21 vs 1.52 ms;
   //  nc = 16, 512^2: 0.98 vs 1.08 ms -- so there the matrix cores take over from 5)
-  if (a.nrhs >= (nc <= 16 ? 5 : 4) && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
+  if (a.nrhs >= (nc <= 16 ? 5 : 4) && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32) && !slab) {   // (kernel C has no halo step: a slab's batches go through kernel B)
     // kernel C: up to 16 right-hand sides per pass share one read of the matrices
     const unsigned gx = (unsigned)((a.hr + BLOCK / WAVE - 1) / (BLOCK / WAVE));
     dim3 grid(gx, gy), block(BLOCK);
@@ -1384,4 +1401,11 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #undef QMG_GEN_CASE3
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
+}
+
+// Generic-nc slab apply (csrc/qmg_site.hip holds the C entry qmg_stencil_apply_slab and serves nc = 2 itself): kernel B with the
+// right-hand side's rows -1 / Ly from the halo buffers.  fp64 only.
+int qmg::generic_slab_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride, const unsigned char* ridx,
+                            hipStream_t st, const SlabHalo* slab) {
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, (size_t)vec_stride, ridx, (void*)st, 0, 0, slab);
 }

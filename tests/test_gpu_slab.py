@@ -239,3 +239,80 @@ def test_slab_solve_with_ranks_emulated_by_threads(L, R):
     assert m1.group(3) == mR.group(3) or abs(float(m1.group(3)) - float(mR.group(3))) < 1e-12 * float(m1.group(3))      # |b|: a sum in another order
     assert abs(float(m1.group(4)) - float(mR.group(4))) < 1e-9 * float(m1.group(4))
     assert abs(int(m1.group(1)) - int(mR.group(1))) <= 2
+
+
+@pytest.mark.parametrize("nc,nrhs,mask", [(8, 1, 1), (8, 3, 0b101), (12, 6, 0b111111), (1, 2, 0b11), (4, 1, 1)])
+def test_generic_nc_slab_apply_through_kernel_B(nc, nrhs, mask):
+    """The Galerkin coarse operators (any nc) on slabs: kernel B with the right-hand side's rows -1 / Ly from the halo buffers
+    reproduces the rows of its own single-domain apply bit for bit (qmg_stencil_apply_slab, nc != 2)."""
+    Lx, Ly, R = 16, 16, 4
+    vol = Lx * Ly
+    n = vol * nc
+    clover, hopping = cs.gaussian_cvec(vol * nc * nc, 1), cs.gaussian_cvec(4 * vol * nc * nc, 2)
+    x, l0 = cs.gaussian_cvec(n * nrhs, 3), cs.gaussian_cvec(n * nrhs, 4)
+    shifts = (0.1 + 0.05j, 0.02, 0.03 if nc % 2 == 0 else 0.0)
+    d = qmg.make_desc(Lx, Ly, nc, D(clover), D(hopping), *shifts)
+    qmg.set_tuning("stencil_mfma", 0)          # the single-domain twin through kernel B as well (kernel C sums in another order)
+    qmg.set_tuning("stencil_pair", 0)
+    try:
+        for pieces in (qmg.P_ALL | qmg.P_ZERO, qmg.P_ALL, qmg.P_OE | qmg.P_ZERO_O):
+            want = D(l0)
+            qmg.stencil_apply_t(qmg.C64, d, want, D(x), pieces, nrhs, n, mask)
+            want = want.to_host()
+            Ll, row = Ly // R, (Lx // 2) * nc
+            nl = Lx * Ll * nc
+            xs = x.reshape(nrhs, 2, Ly, row)
+            for r in range(R):
+                y0 = r * Ll
+                dl = qmg.make_desc(Lx, Ll, nc, D(rows(clover, Ly, (Lx // 2) * nc * nc, y0, Ll)), D(rows(hopping, Ly, (Lx // 2) * nc * nc, y0, Ll)), *shifts)
+                dx = D(np.concatenate([rows(x[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+                out = D(np.concatenate([rows(l0[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+                lo, hi = D(xs[:, :, (y0 - 1) % Ly].reshape(-1)), D(xs[:, :, (y0 + Ll) % Ly].reshape(-1))
+                qmg.stencil_apply_slab(qmg.C64, dl, out, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=0)
+                got = out.to_host()
+                for k in range(nrhs):
+                    if nc in (1, 4):    # single-domain nc = 1, 4 run kernel A (other summation order): 1e-14 instead of bit equality
+                        assert cs.rel_l2(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], Ly, row, y0, Ll)) < 1e-14
+                    else:
+                        assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], Ly, row, y0, Ll)), (nc, r, hex(pieces), k)
+    finally:
+        qmg.set_tuning("stencil_mfma", 1)
+        qmg.set_tuning("stencil_pair", 2)
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_galerkin_build_and_gaussian_on_slabs(R):
+    """Setup on slabs: the block-local Galerkin build with the null vectors' halo rows gives the slab's rows of the single-domain
+    coarse operator bit for bit, and qmg_gaussian_slab draws the slab's rows of the single-domain Gaussian vector."""
+    L, nvec = 32, 8
+    cL = L // 4
+    vol = L * L
+    g = D(random_gauge(L, 4))
+    cl, hp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
+    qmg.wilson_fill(cl, hp, g, L, L, 1.0)
+    fsize = 2 * vol
+    P = cs.gaussian_cvec(nvec * fsize, 21)
+    dP = D(P)
+    qmg.block_orthonormalize(dP, nvec, (L, L, 2), cL, cL)
+    P = dP.to_host()
+    cc, ch = qmg.DeviceArray(cL * cL * nvec * nvec), qmg.DeviceArray(4 * cL * cL * nvec * nvec)
+    qmg.coarse_build(cc, ch, qmg.make_desc(L, L, 2, cl, hp, 0.0), dP, (cL, cL, nvec))
+    want_c, want_h = cc.to_host(), ch.to_host()
+    cl_h, hp_h = cl.to_host(), hp.to_host()
+    Ll, cLl, row = L // R, cL // R, L
+    Ps = P.reshape(nvec, 2, L, row)
+    for r in range(R):
+        y0 = r * Ll
+        Pl = D(np.concatenate([rows(P[v * fsize:(v + 1) * fsize], L, row, y0, Ll) for v in range(nvec)]))
+        lo, hi = D(Ps[:, :, (y0 - 1) % L].reshape(-1)), D(Ps[:, :, (y0 + Ll) % L].reshape(-1))
+        dl = qmg.make_desc(L, Ll, 2, D(rows(cl_h, L, (L // 2) * 4, y0, Ll)), D(rows(hp_h, L, (L // 2) * 4, y0, Ll)), 0.0)
+        sc, sh = qmg.DeviceArray(cL * cLl * nvec * nvec), qmg.DeviceArray(4 * cL * cLl * nvec * nvec)
+        qmg.coarse_build_slab(sc, sh, dl, Pl, (cL, cLl, nvec), lo, hi, 2 * row)
+        per = (cL // 2) * nvec * nvec
+        assert np.array_equal(sc.to_host(), rows(want_c, cL, per, r * cLl, cLl)), r
+        assert np.array_equal(sh.to_host(), rows(want_h, cL, per, r * cLl, cLl)), r
+        v = qmg.DeviceArray(2 * L * Ll)
+        qmg.gaussian_slab(v, L, L, y0, Ll, 2, 99)
+        full = qmg.DeviceArray(2 * vol)
+        qmg.gaussian(full, 2 * vol, 99)
+        assert np.array_equal(v.to_host(), rows(full.to_host(), L, row, y0, Ll))
