@@ -101,7 +101,10 @@ inline int N13::build(int argc, char** argv) {
   }
   cout << setprecision(20);
   // one process per GPU: the launcher's LOCAL_RANK picks the device (torchrun sets it); a single process uses device 0
-  if (!qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
+  // (y-slab mode, n13_wilson_kcycle_slab: the caller has initialised the device and the communicator and called qmg::slab_begin())
+  const bool dd = qmg::slab().on;
+  const bool root = !dd || qmg::slab().rank == 0;
+  if (!dd && !qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
   if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   x_len = stoi(argv[1]); y_len = stoi(argv[1]);
   mass = stod(argv[2]);
@@ -111,8 +114,8 @@ inline int N13::build(int argc, char** argv) {
   coarse_dof = (argc > 5) ? stoi(argv[5]) : 8;
   const string gauge_file = (argc > 6) ? argv[6] : "../../tests/golden/l64t64b60_heatbath.dat";
   const int tile = (argc > 7) ? stoi(argv[7]) : 64;
-  quiet = getenv("QMG_QUIET") != 0;
-  dump_dir = getenv("QMG_DUMP_DIR");   // test hook: null vectors, rhs and solution as raw complex128
+  quiet = getenv("QMG_QUIET") != 0 || !root;
+  dump_dir = dd ? 0 : getenv("QMG_DUMP_DIR");   // test hook: null vectors, rhs and solution as raw complex128
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4;
   tol = 1e-10; max_iter = 1000; restart_freq = 32;
@@ -127,16 +130,26 @@ inline int N13::build(int argc, char** argv) {
   int null_batch = getenv("QMG_NULL_BATCH") ? atoi(getenv("QMG_NULL_BATCH")) : 8;
   if (null_batch < 1) null_batch = 1;
   if (null_batch > qmg::BATCH_MAX) null_batch = qmg::BATCH_MAX;
+  if (dd) null_batch = 1;   // slabs: the relaxations run one at a time in the reference's order (the batch kernels have no halo step yet)
   const bool null_f32 = getenv("QMG_NULL_F32") ? atoi(getenv("QMG_NULL_F32")) != 0 : true;
 
-  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verbosity = !root ? VERB_NONE : quiet ? VERB_SUMMARY : VERB_DETAIL;
   verb.verb_prefix = "Level 0: ";
-  verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.precond_verbosity = (quiet || !root) ? VERB_NONE : VERB_SUMMARY;
   verb.precond_verb_prefix = "Prec ";
   inversion_verbose_struct verb_null(VERB_NONE, "");
 
+  // y-slab mode: this rank holds y_len / world rows of every level; the slab must stay a whole, even number of block rows down to the coarsest level
+  const int world = dd ? qmg::slab().world : 1;
+  int y_loc = y_len / world;
+  {
+    int rows = y_loc;
+    bool fits = (y_len % world == 0) && !(rows & 1);
+    for (int i = 0; i < n_refine && fits; i++) { fits = (rows % y_block == 0); rows /= y_block; fits = fits && !(rows & 1) && rows >= 2; }
+    if (!fits) { if (root) std::cout << "[QMG-ERROR]: " << y_len << " rows do not split into " << world << " slabs of whole, even block rows on every level.\n"; return 4; }
+  }
   lats = new Lattice2D*[n_refine + 1];
-  lats[0] = new Lattice2D(x_len, y_len, dof);
+  lats[0] = new Lattice2D(x_len, y_loc, dof);
   Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
   gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
   bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
@@ -153,10 +166,10 @@ inline int N13::build(int argc, char** argv) {
   coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
   mg_object = new StatefulMultigridMG(lats[0], wilson_op, coarsest_solve_obj);
 
-  int curr_x_len = x_len, curr_y_len = y_len;
+  int curr_x_len = x_len, curr_y_len = y_loc;
   transfer_objs = new TransferMG*[n_refine];
   double t_null = 0.0, t_ortho = 0.0, t_galerkin = 0.0;   // setup split: null-vector relaxation / block orthonormalisation / Galerkin build
-  auto now = [] { qmg_stream_sync(0); return std::chrono::steady_clock::now(); };
+  auto now = [] { qmg_stream_sync(qmg::current_stream()); return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   for (int i = 1; i <= n_refine; i++) {
     curr_x_len /= x_block; curr_y_len /= y_block;
@@ -172,7 +185,7 @@ inline int N13::build(int argc, char** argv) {
     } else
     for (int j = 0; j < coarse_dof / 2; j++) {
       complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
-      gaussian(rand_guess, fsize, seed++);
+      gaussian_lattice(rand_guess, lats[i - 1]->get_dim_mu(0), lats[i - 1]->get_dim_mu(1), lats[i - 1]->get_nc(), seed++);
       for (int k = 0; k < j; k++) orthogonal(rand_guess, null_vectors[k], fsize);
       complex<double>* Arand_guess = mg_object->get_storage(i - 1)->check_out();
       zero_vector(Arand_guess, fsize);
@@ -215,11 +228,11 @@ inline int N13::build(int argc, char** argv) {
     t_null += secs(t0, t1); t_ortho += secs(t1, t2); t_galerkin += secs(t2, t3);
     for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
     delete[] null_vectors;
-    cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
+    if (root) cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
   }
   qmg_stream_sync(0);
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
-  cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
+  if (root) cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
        << " s ; total " << setup_s << " s\n" << setprecision(20);
 
   return 0;

@@ -66,6 +66,18 @@ struct CoarseOperator2D : public Stencil2D {
     // an ORIGINAL-built coarse operator keep the mass term (facade_selftest checks apply_M before and after a dagger swap).
     shift = shift_backup = fine_stencil->get_shift();
     qmg_stencil_desc fd = fine_stencil->desc();
+    if (qmg::slab().on) {   // the hops that leave the slab need the neighbouring ranks' rows of the prolongator
+      const int nv = lat->get_nc();
+      const size_t hs = (size_t)fd.Lx * fd.nc;
+      complex<double>*lo = allocate_vector<complex<double>>(hs * nv), *hi = allocate_vector<complex<double>>(hs * nv);
+      if (use_rbjacobi) std::cout << "[QMG-ERROR]: Galerkin builds from the right-block-Jacobi stencil are not decomposed into slabs yet.\n";
+      qmg::ok(qmg_halo_exchange(QMG_C64, transfer->device_null_vectors(), fd.Lx, fd.Ly, fd.nc, lo, hi, nv, (size_t)fine_lattice->get_size_cv_l(), hs, qmg::current_stream()),
+              "qmg_halo_exchange");
+      qmg::ok(qmg_coarse_build_slab(clover, hopping, &fd, transfer->device_null_vectors(), transfer->device_restrict_vectors(), lat->get_dim_mu(0), lat->get_dim_mu(1),
+                                    lat->get_nc(), lo, hi, hs, qmg::current_stream()), "qmg_coarse_build_slab");
+      qmg::ok(qmg_stream_sync(qmg::current_stream()), "qmg_stream_sync");
+      deallocate_vector(&lo); deallocate_vector(&hi);
+    } else
     qmg::ok(qmg_coarse_build(clover, hopping, &fd, transfer->device_null_vectors(), transfer->device_restrict_vectors(), lat->get_dim_mu(0),
                              lat->get_dim_mu(1), lat->get_nc(), qmg::current_stream()), "qmg_coarse_build");
     if (use_rbjacobi) fine_stencil->perform_swap_rbjacobi();

@@ -35,8 +35,12 @@ struct Wilson2D : public Stencil2D {
   }
 
  public:
-  void update_links(complex<double>* gauge_links) {   // wilson.h:153-226; gauge_links: DEVICE nc=1 LatticeGauge
-    qmg::ok(qmg_wilson_fill(clover, hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1), wilson_coeff, qmg::current_stream()), "qmg_wilson_fill");
+  void update_links(complex<double>* gauge_links) {   // wilson.h:153-226; gauge_links: DEVICE nc=1 LatticeGauge (y-slab mode: of the WHOLE lattice)
+    if (qmg::slab().on)
+      qmg::ok(qmg_wilson_fill_slab(clover, hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1) * qmg::slab().world, qmg::slab().rank * lat->get_dim_mu(1),
+                                   lat->get_dim_mu(1), wilson_coeff, qmg::current_stream()), "qmg_wilson_fill_slab");
+    else
+      qmg::ok(qmg_wilson_fill(clover, hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1), wilson_coeff, qmg::current_stream()), "qmg_wilson_fill");
     if (built_dagger) { deallocate_vector(&dagger_clover); deallocate_vector(&dagger_hopping); built_dagger = false; }
     if (built_rbjacobi) { deallocate_vector(&rbjacobi_cinv); deallocate_vector(&rbjacobi_clover); deallocate_vector(&rbjacobi_hopping); built_rbjacobi = false; }
     // (the reference leaves a built rbj_dagger stencil dangling here, wilson.h:211-225; it is dropped too)

@@ -37,6 +37,22 @@ inline void*& current_stream() {
   return s;
 }
 
+// ---- y-slab mode of this host thread ----
+// Off: every Lattice2D is a whole periodic lattice (the reference's semantics).  On: every Lattice2D of this thread is the
+// slab [rank Ly, (rank + 1) Ly) of a lattice with world x Ly rows; operator applies exchange halo rows with the neighbouring
+// ranks (Stencil2D::launch), the Galerkin build exchanges the null vectors' halo rows (CoarseOperator2D), reductions are
+// summed over the ranks inside the library, and gaussian_lattice draws the slab's rows of the single-domain vector.
+// Everything else (BLAS-1, transfer, block orthonormalisation, the solvers) is slab-local and unchanged.
+struct SlabContext { bool on; int world, rank; };
+inline SlabContext& slab() { static thread_local SlabContext c = {false, 1, 0}; return c; }
+inline bool slab_begin() {   // after qmg_comm_init_env (or qmg_comm_emulate_attach)
+  int w = 1, r = 0;
+  if (!ok(qmg_comm_world(&w, &r), "qmg_comm_world")) return false;
+  slab() = {true, w, r};
+  return ok(qmg_comm_set_distributed_reductions(1), "qmg_comm_set_distributed_reductions");
+}
+inline void slab_end() { slab() = {false, 1, 0}; qmg_comm_set_distributed_reductions(0); }
+
 // ---- staging helpers (host <-> device); the reference has no such step, tests index arrays directly ----
 template <typename T> inline void upload(T* dev, const T* host, size_t n) { ok(qmg_memcpy_h2d(dev, host, n * sizeof(T), nullptr), "qmg_memcpy_h2d"); }
 template <typename T> inline void download(T* host, const T* dev, size_t n) {
@@ -102,6 +118,14 @@ inline void normalize(qmg_c* v, size_t n) {
 // (not portable across standard libraries); here a counter-based device generator keyed
 // by `seed` -- same distribution, different stream of numbers.
 inline void gaussian(qmg_c* x, size_t n, unsigned long long seed) { qmg::ok(qmg_gaussian(x, n, seed, qmg::current_stream()), "gaussian"); }
+// a Gaussian vector on a lattice (Lx x Ly rows held here, nc per site): in y-slab mode the slab's rows of the vector the
+// single-domain run draws with the same seed -- a decomposed run then works on the very same vectors
+inline void gaussian_lattice(qmg_c* x, int Lx, int Ly, int nc, unsigned long long seed) {
+  if (qmg::slab().on)
+    qmg::ok(qmg_gaussian_slab(x, Lx, Ly * qmg::slab().world, qmg::slab().rank * Ly, Ly, nc, seed, qmg::current_stream()), "qmg_gaussian_slab");
+  else
+    qmg::ok(qmg_gaussian(x, (size_t)Lx * Ly * nc, seed, qmg::current_stream()), "gaussian");
+}
 
 // ---- verbosity / result structs of quantum-linalg (fields as used at stateful_multigrid.h:762-776, n13:125-132,464-466) ----
 enum inversion_verbose_level { VERB_NONE = 0, VERB_SUMMARY = 1, VERB_RESTART_DETAIL = 2, VERB_DETAIL = 3 };

@@ -71,6 +71,7 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (qmg::slab().on) { launch_slab(d, pieces, lhs, rhs, direct_usable(cl, ho)); return; }
     if (direct_usable(cl, ho)) {   // straight from the links where that serves the piece set
       const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, 1, 0, 0, 1u, 0, qmg::current_stream());
       if (rc == QMG_SUCCESS) return;
@@ -117,12 +118,33 @@ struct Stencil2D {
   struct DirectLinks {
     complex<double>* gauge; void* gauge32; double w; bool on;
   } direct;
+  // y-slab mode (qmg::slab()): the halo rows of the right-hand side of an apply, [parity][Lx/2][nc] each
+  complex<double>*slab_halo_lo, *slab_halo_hi;
+  bool slab_halos() {
+    if (!slab_halo_lo) slab_halo_lo = allocate_vector<complex<double>>((size_t)lat->get_dim_mu(0) * lat->get_nc());
+    if (!slab_halo_hi) slab_halo_hi = allocate_vector<complex<double>>((size_t)lat->get_dim_mu(0) * lat->get_nc());
+    return slab_halo_lo && slab_halo_hi;
+  }
+  // one system on a slab: exchange the halo rows of rhs with the neighbouring ranks, then apply with them
+  void launch_slab(const qmg_stencil_desc& d, unsigned pieces, complex<double>* lhs, complex<double>* rhs, bool original_arrays) {
+    if (!slab_halos()) { std::cout << "[QMG-ERROR]: no memory for the halo rows\n"; return; }
+    const size_t hs = (size_t)d.Lx * d.nc;
+    void* st = qmg::current_stream();
+    if (!qmg::ok(qmg_halo_exchange(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, st), "qmg_halo_exchange")) return;
+    if (original_arrays && direct.on) {   // Wilson straight from the (global, replicated) links
+      const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs, slab_halo_lo,
+                                             slab_halo_hi, pieces, 1, 0, hs, 1u, 0, st);
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+    }
+    qmg::ok(qmg_stencil_apply_slab(QMG_C64, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, 1, 0, hs, 1u, 0, st), "qmg_stencil_apply_slab");
+  }
   bool direct_usable(const complex<double>* cl, const complex<double>* ho) const {
     return direct.on && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
   }
   void set_direct_links(const complex<double>* gauge_links, double w) {   // copies the links (the caller's array may change)
     static const bool enabled = !(getenv("QMG_WILSON_DIRECT") && atoi(getenv("QMG_WILSON_DIRECT")) == 0);
-    const size_t n = (size_t)2 * lat->get_volume();
+    const size_t n = (size_t)2 * lat->get_volume() * (qmg::slab().on ? qmg::slab().world : 1);   // a slab keeps the links of the WHOLE lattice (32 B/site)
     if (!enabled || lat->get_nc() != 2) { direct.on = false; return; }
     if (!direct.gauge) direct.gauge = allocate_vector<complex<double>>(n);
     if (!direct.gauge) { direct.on = false; return; }
@@ -168,6 +190,7 @@ struct Stencil2D {
     f32_matrices = false; clover32 = hopping32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
     direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false;
+    slab_halo_lo = slab_halo_hi = 0;
     f32.clover16 = f32.hopping16 = f32.rbj_hopping16 = 0; f32.half_on = false;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
@@ -185,6 +208,8 @@ struct Stencil2D {
     disable_f32_matrices();
     disable_f32_shadow();
     drop_direct_links();
+    if (slab_halo_lo) deallocate_vector(&slab_halo_lo);
+    if (slab_halo_hi) deallocate_vector(&slab_halo_hi);
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
   }
 
@@ -390,6 +415,16 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    if (qmg::slab().on) {   // slabs: one system at a time through the halo path (fp64 only this round)
+      if (sizeof(T) != sizeof(double)) { std::cout << "[QMG-ERROR]: fp32 batches are not decomposed into slabs yet.\n"; return; }
+      d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
+      d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
+      for (int k = 0; k < nrhs; k++)
+        if ((mask >> k) & 1u)
+          launch_slab(d, pieces, reinterpret_cast<complex<double>*>(lhs) + (size_t)k * stride, reinterpret_cast<complex<double>*>(rhs) + (size_t)k * stride,
+                      set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping));
+      return;
+    }
     if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (sizeof(T) == sizeof(double) || direct.gauge32)) {
       const int rc = qmg_wilson_apply_direct(sizeof(T) == sizeof(float) ? QMG_C32 : QMG_C64, &d, sizeof(T) == sizeof(float) ? direct.gauge32 : (void*)direct.gauge,
                                              d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, nrhs, stride, 0, mask, 0, qmg::current_stream());
