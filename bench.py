@@ -476,6 +476,37 @@ def slab_solve(L, world, rank):
             "note": "each rank also builds the single-domain operator once and checks its slab apply (real exchange) against its rows of it"}
 
 
+def slab_kcycle(L, world, rank):
+    """SURVEY 8f-4, the multigrid half: the n13 K-cycle (3 levels, 4x4 blocks, coarse nc = 8, the reference's constants) with ONE L x L lattice
+    cut into `world` y-slabs on EVERY level (drivers/n13_wilson_kcycle_slab.cpp).  Every rank starts its child; rank 0's child reports.  The
+    decomposed run draws the single-domain run's random vectors, so `outer_iterations` and `x_norm2` must agree across the driver's
+    N = 1, 2, 4, 8 runs and `solve_s` / `setup_s` are the strong-scaling curves.  (Null vectors are relaxed one at a time in fp64 here --
+    the batched fp32 relaxation of `also_kcycle` has no halo step yet -- so `setup_s` is not comparable with that line.)"""
+    import re
+    import subprocess
+    drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+    exe = os.path.join(drivers, "n13_wilson_kcycle_slab")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
+    try:
+        p = subprocess.run([exe, str(L), str(MASS), "6.0", "2", "8", fixture, "64"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"error": "n13_wilson_kcycle_slab timed out after 300 s on rank %d" % rank}
+    if rank != 0:
+        return None
+    m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
+    c = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
+    sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", p.stdout)
+    t = re.search(r"\[QMG-TIMING\]: setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
+    if not (m and c and sl and t) or p.returncode != 0:
+        return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
+    return {"workload": "Wilson K-cycle (n13 parameters), %dx%d, 3 levels, coarse nc=8, fp64, ONE lattice cut into %d y-slab(s) on every level" % (L, L, world),
+            "scaling": "strong", "world": int(sl.group(1)), "converged": m.group(1) == "converged", "outer_iterations": int(m.group(2)),
+            "true_residual": float(c.group(1)), "x_norm2": float(sl.group(3)), "setup_s": float(t.group(1)), "solve_s": float(t.group(2)),
+            "outer_iterations_per_s": float(t.group(3))}
+
+
 def pmc_traffic(L):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes, ONLY if they were taken on the
     kernel source that is being run now (sha256 of csrc/qmg_stencil.hip stamped by tools/summarize_profiles.py)."""
@@ -740,8 +771,12 @@ def main():
     if not args.no_also:   # every rank takes part: the slabs of one lattice
         barrier()
         slab = slab_solve(L, world, rank)
+        barrier()
+        slab_k = slab_kcycle(2048, world, rank) if not args.no_kcycle else None
         if rank == 0:
             out["also_slab_solve"] = slab
+            if slab_k is not None:
+                out["also_slab_kcycle"] = slab_k
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fixture)

@@ -316,3 +316,38 @@ def test_galerkin_build_and_gaussian_on_slabs(R):
         full = qmg.DeviceArray(2 * vol)
         qmg.gaussian(full, 2 * vol, 99)
         assert np.array_equal(v.to_host(), rows(full.to_host(), L, row, y0, Ll))
+
+
+@pytest.mark.parametrize("L,levels,nc,R", [(128, 2, 8, 2), (128, 2, 8, 4), (256, 2, 8, 8), (128, 1, 24, 4)])
+def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R):
+    """The whole n13 K-cycle with ONE lattice cut into R y-slabs (drivers/n13_wilson_kcycle_slab.cpp, facade slab mode): setup
+    (null-vector relaxation, block orthonormalisation, Galerkin build with the prolongator's halo rows) and solve on every level
+    decomposed, ranks emulated by host threads.  The decomposed run draws the single-domain run's random vectors (gaussian_lattice),
+    so it must FOLLOW the single-domain n13 driver (same sequential fp64 null-vector relaxation): same outer iteration count, the
+    same right-hand side, the same solution norm to 1e-10, true residual below tolerance -- only the rounding of the reductions
+    (per-slab partial sums) differs."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    args = [str(L), "-0.05", "6.0", str(levels), str(nc), gauge, "64"]
+    env = dict(os.environ, QMG_QUIET="1", QMG_NULL_BATCH="1")
+    plain = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle")] + args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    for o in (plain, one, many):
+        assert o.returncode == 0, o.stdout[-2500:] + o.stderr[-1500:]
+    it = lambda o: int(re.search(r"Multigrid converged in (\d+) iterations", o.stdout).group(1))
+    chk = lambda o: float(re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1))
+    slab = lambda o: [float(v) for v in re.search(r"\[QMG-SLAB\]: world \d+ ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", o.stdout).groups()]
+    # one rank in slab mode IS the single-domain run (its exchanges are device copies): identical to the plain driver
+    assert it(one) == it(plain) and chk(one) == chk(plain)
+    assert it(many) == it(one), (it(many), it(one))
+    assert chk(many) < 1e-9
+    b1, x1 = slab(one)
+    bR, xR = slab(many)
+    assert abs(bR - b1) < 1e-13 * b1 and abs(xR - x1) < 1e-10 * x1, (b1, bR, x1, xR)
+    assert "world %d" % R in many.stdout
