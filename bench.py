@@ -480,8 +480,7 @@ def slab_kcycle(L, world, rank):
     """SURVEY 8f-4, the multigrid half: the n13 K-cycle (3 levels, 4x4 blocks, coarse nc = 8, the reference's constants) with ONE L x L lattice
     cut into `world` y-slabs on EVERY level (drivers/n13_wilson_kcycle_slab.cpp).  Every rank starts its child; rank 0's child reports.  The
     decomposed run draws the single-domain run's random vectors, so `outer_iterations` and `x_norm2` must agree across the driver's
-    N = 1, 2, 4, 8 runs and `solve_s` / `setup_s` are the strong-scaling curves.  (Null vectors are relaxed one at a time in fp64 here --
-    the batched fp32 relaxation of `also_kcycle` has no halo step yet -- so `setup_s` is not comparable with that line.)"""
+    N = 1, 2, 4, 8 runs (to the rounding of the fp32 setup) and `solve_s` / `setup_s` are the strong-scaling curves."""
     import re
     import subprocess
     drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")

@@ -327,7 +327,7 @@ int qmg_stencil_apply_h16(const qmg_stencil_desc* d, void* lhs, const void* rhs,
 // halo_lo / halo_hi (filled by qmg_halo_exchange).  storage: QMG_C64, QMG_C32, or QMG_C32 | QMG_SLAB_H16 for 16-bit stored
 // matrices.  rows: 0 = all, 1 = interior rows only (need no halo: they can run while the exchange is in flight),
 // 2 = the two boundary rows.  nc = 2: kernel S in any storage and any `rows`; other nc (the Galerkin coarse operators): kernel B,
-// fp64, rows = 0 (QMG_ERR_UNSUPPORTED otherwise).
+// fp64 or fp32, rows = 0 (QMG_ERR_UNSUPPORTED otherwise).
 int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi,
                            unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows, void* stream) {
   if (!d || !lhs || !rhs || !halo_lo || !halo_hi || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2 || lhs == rhs) return QMG_ERR_INVALID;
@@ -343,9 +343,9 @@ int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, co
   if (n == 0) return QMG_SUCCESS;
   SlabHalo slab;
   slab.lo = halo_lo; slab.hi = halo_hi; slab.stride = (long)halo_stride; slab.rows = rows;
-  if (d->nc != 2) {   // any other nc: kernel B (fp64, all rows in one launch)
-    if (h16 || dtype != QMG_C64 || rows != 0) return QMG_ERR_UNSUPPORTED;
-    return generic_slab_apply(d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), &slab);
+  if (d->nc != 2) {   // any other nc: kernel B (all rows in one launch)
+    if (h16 || rows != 0) return QMG_ERR_UNSUPPORTED;
+    return generic_slab_apply(d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), &slab, dtype == QMG_C32 ? 1 : 0);
   }
   return site_kernel_apply(h16 ? 0 : (dtype == QMG_C32 ? 1 : 2), d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), false, &slab);
 }

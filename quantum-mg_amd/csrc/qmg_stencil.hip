@@ -1213,7 +1213,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.vec32 = vec32;
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
-  if (slab && (mat32 != vec32 || (mat32 && nc != 2))) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2, either precision) or kernel B (fp64)
+  if (slab && mat32 != vec32) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2) or kernel B (any nc), matrices and vectors in ONE precision
   if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
     const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !slab && !(g_stencil_site & 4), slab);
     if (rc != SITE_DECLINED) return rc;
@@ -1343,7 +1343,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   }
 
   if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
-  if (a.mat32 && !(nc & 1) && g_gen32) {
+  if (a.mat32 && !(nc & 1) && g_gen32 && !slab) {   // (kernel B32 has no halo step: a slab's fp32 applies go through kernel B's widening loads)
     // kernel B32: fp32 tile end to end (even nc)
     const GenLayout L = make_gen_layout(nc, a.hr, g_gen32 == 2 ? 1 : 0);
     const int pp = (L.mat_elems / 2 + BLOCK - 1) / BLOCK;
@@ -1404,8 +1404,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 }
 
 // Generic-nc slab apply (csrc/qmg_site.hip holds the C entry qmg_stencil_apply_slab and serves nc = 2 itself): kernel B with the
-// right-hand side's rows -1 / Ly from the halo buffers.  fp64 only.
+// right-hand side's rows -1 / Ly from the halo buffers, in fp64 or with complex<float> matrices and vectors.
 int qmg::generic_slab_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride, const unsigned char* ridx,
-                            hipStream_t st, const SlabHalo* slab) {
-  return stencil_apply_impl(d, lhs, rhs, pieces, n, (size_t)vec_stride, ridx, (void*)st, 0, 0, slab);
+                            hipStream_t st, const SlabHalo* slab, int f32) {
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, (size_t)vec_stride, ridx, (void*)st, f32, f32, slab);
 }

@@ -36,7 +36,7 @@ inline bool relax_null_vectors_batched(Stencil2D* st, complex<double>** null_vec
     if (!G.p || !B.p || !X.p) { std::cout << "[QMG-ERROR]: no memory for a batch of " << nb << " null vectors\n"; return false; }
     for (int k = 0; k < nb; k++) {
       complex<double>* g = null_vectors[j0 + k];
-      gaussian(g, fsize, seed++);
+      gaussian_lattice(g, st->lat->get_dim_mu(0), st->lat->get_dim_mu(1), st->lat->get_nc(), seed++);
       for (int m = 0; m < j0; m++) orthogonal(g, null_vectors[m], fsize);
       qmg::ok(qmg_convert(G.vec(k), qmg::dtype_of<T>::value, g, QMG_C64, (size_t)fsize, qmg::current_stream()), "qmg_convert");
     }
@@ -130,7 +130,6 @@ inline int N13::build(int argc, char** argv) {
   int null_batch = getenv("QMG_NULL_BATCH") ? atoi(getenv("QMG_NULL_BATCH")) : 8;
   if (null_batch < 1) null_batch = 1;
   if (null_batch > qmg::BATCH_MAX) null_batch = qmg::BATCH_MAX;
-  if (dd) null_batch = 1;   // slabs: the relaxations run one at a time in the reference's order (the batch kernels have no halo step yet)
   const bool null_f32 = getenv("QMG_NULL_F32") ? atoi(getenv("QMG_NULL_F32")) != 0 : true;
 
   verb.verbosity = !root ? VERB_NONE : quiet ? VERB_SUMMARY : VERB_DETAIL;

@@ -120,9 +120,9 @@ struct Stencil2D {
   } direct;
   // y-slab mode (qmg::slab()): the halo rows of the right-hand side of an apply, [parity][Lx/2][nc] each
   complex<double>*slab_halo_lo, *slab_halo_hi;
-  bool slab_halos() {
-    if (!slab_halo_lo) slab_halo_lo = allocate_vector<complex<double>>((size_t)lat->get_dim_mu(0) * lat->get_nc());
-    if (!slab_halo_hi) slab_halo_hi = allocate_vector<complex<double>>((size_t)lat->get_dim_mu(0) * lat->get_nc());
+  bool slab_halos() {   // room for the halo rows of a full batch (16 systems)
+    if (!slab_halo_lo) slab_halo_lo = allocate_vector<complex<double>>((size_t)16 * lat->get_dim_mu(0) * lat->get_nc());
+    if (!slab_halo_hi) slab_halo_hi = allocate_vector<complex<double>>((size_t)16 * lat->get_dim_mu(0) * lat->get_nc());
     return slab_halo_lo && slab_halo_hi;
   }
   // one system on a slab: exchange the halo rows of rhs with the neighbouring ranks, then apply with them
@@ -235,8 +235,8 @@ struct Stencil2D {
       if (good && built_rbjacobi) good = dup16(&f32.rbj_hopping16, rbjacobi_hopping, lat->get_size_hopping_l());
       f32.half_on = good;
     }
-    if (good && direct.on && !direct.gauge32) {   // the links of a direct-apply operator in fp32 as well (8 B/site)
-      const size_t n = (size_t)2 * lat->get_volume();
+    if (good && direct.on && !direct.gauge32) {   // the links of a direct-apply operator in fp32 as well (8 B/site; slab mode: of the whole lattice)
+      const size_t n = (size_t)2 * lat->get_volume() * (qmg::slab().on ? qmg::slab().world : 1);
       if (qmg_malloc(&direct.gauge32, n * 8) == QMG_SUCCESS) qmg::ok(qmg_convert(direct.gauge32, QMG_C32, direct.gauge, QMG_C64, n, qmg::current_stream()), "qmg_convert");
       else direct.gauge32 = 0;
     }
@@ -415,14 +415,28 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
-    if (qmg::slab().on) {   // slabs: one system at a time through the halo path (fp64 only this round)
-      if (sizeof(T) != sizeof(double)) { std::cout << "[QMG-ERROR]: fp32 batches are not decomposed into slabs yet.\n"; return; }
-      d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
-      d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
-      for (int k = 0; k < nrhs; k++)
-        if ((mask >> k) & 1u)
-          launch_slab(d, pieces, reinterpret_cast<complex<double>*>(lhs) + (size_t)k * stride, reinterpret_cast<complex<double>*>(rhs) + (size_t)k * stride,
-                      set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping));
+    if (qmg::slab().on) {   // slabs: ONE exchange of the batch's halo rows, one launch with them (kernel W / S on nc = 2, kernel B otherwise)
+      const bool f = sizeof(T) == sizeof(float);
+      const int dt = f ? QMG_C32 : QMG_C64;
+      if (f && !f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
+      if (nrhs > 16 || !slab_halos()) { std::cout << "[QMG-ERROR]: a slab batch is at most 16 systems\n"; return; }
+      const size_t hs = (size_t)d.Lx * d.nc;
+      void* st = qmg::current_stream();
+      if (!qmg::ok(qmg_halo_exchange(dt, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, nrhs, stride, hs, st), "qmg_halo_exchange")) return;
+      if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (!f || direct.gauge32)) {
+        const int rc = qmg_wilson_apply_direct(dt, &d, f ? direct.gauge32 : (void*)direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs,
+                                               slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st);
+        if (rc == QMG_SUCCESS) return;
+        if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+      }
+      if (f) {
+        d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
+        d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+      } else {
+        d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
+        d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
+      }
+      qmg::ok(qmg_stencil_apply_slab(dt, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
       return;
     }
     if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (sizeof(T) == sizeof(double) || direct.gauge32)) {

@@ -168,17 +168,24 @@ def test_library_exchange_on_one_rank_is_the_periodic_wrap(monkeypatch, forced_r
 def test_slab_entry_points_refuse_what_they_do_not_serve():
     import ctypes as C
     L = 16
-    cl, hp, v = qmg.DeviceArray(16 * L * L), qmg.DeviceArray(64 * L * L), qmg.DeviceArray(4 * L * L)
+    cl, hp = qmg.DeviceArray(16 * L * L), qmg.DeviceArray(64 * L * L)
+    x, y = qmg.DeviceArray(4 * L * L), qmg.DeviceArray(4 * L * L)
     halo = qmg.DeviceArray(4 * L)
     d4 = qmg.make_desc(L, L, 4, cl, hp)
     lib = qmg.lib()
-    args = (C.c_void_p(v.ptr), C.c_void_p(v.ptr + 16 * 2 * L * L), C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), C.c_uint(0xFFF), 1, C.c_size_t(0), C.c_size_t(0),
-            C.c_uint(1), 0, None)
-    assert lib.qmg_stencil_apply_slab(qmg.C64, C.byref(d4), *args) == 3                      # nc = 4: unsupported this round
+
+    def call(storage, desc, rows=0):
+        return lib.qmg_stencil_apply_slab(storage, C.byref(desc), C.c_void_p(y.ptr), C.c_void_p(x.ptr), C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), C.c_uint(0xFFF), 1,
+                                          C.c_size_t(0), C.c_size_t(0), C.c_uint(1), rows, None)
+    assert call(qmg.C64, d4) == 0                                # any nc: kernel B with halos
+    assert call(qmg.C64, d4, rows=1) == 3                        # ... but only all rows in one launch
+    assert call(qmg.C32 | qmg.SLAB_H16, d4) == 3                 # 16-bit matrices are an nc = 2 format
     d2 = qmg.make_desc(L, L, 2, cl, hp)
-    assert lib.qmg_stencil_apply_slab(qmg.C64 | qmg.SLAB_H16, C.byref(d2), *args) == 1       # 16-bit matrices come with fp32 vectors
-    assert lib.qmg_stencil_apply_slab(7, C.byref(d2), *args) == 1
-    assert lib.qmg_halo_exchange(qmg.C64, C.c_void_p(v.ptr), L, 15, 2, C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), 1, C.c_size_t(0), C.c_size_t(0), None) == 1
+    assert call(qmg.C64 | qmg.SLAB_H16, d2) == 1                 # 16-bit matrices come with fp32 vectors
+    assert call(7, d2) == 1
+    assert lib.qmg_stencil_apply_slab(qmg.C64, C.byref(d2), C.c_void_p(x.ptr), C.c_void_p(x.ptr), C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), C.c_uint(0xFFF), 1,
+                                      C.c_size_t(0), C.c_size_t(0), C.c_uint(1), 0, None) == 1          # in place
+    assert lib.qmg_halo_exchange(qmg.C64, C.c_void_p(x.ptr), L, 15, 2, C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), 1, C.c_size_t(0), C.c_size_t(0), None) == 1
 
 
 @pytest.mark.parametrize("forced_rccl", [False, True])
@@ -318,14 +325,17 @@ def test_galerkin_build_and_gaussian_on_slabs(R):
         assert np.array_equal(v.to_host(), rows(full.to_host(), L, row, y0, Ll))
 
 
-@pytest.mark.parametrize("L,levels,nc,R", [(128, 2, 8, 2), (128, 2, 8, 4), (256, 2, 8, 8), (128, 1, 24, 4)])
-def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R):
+@pytest.mark.parametrize("L,levels,nc,R,batched", [(128, 2, 8, 2, False), (128, 2, 8, 4, False), (256, 2, 8, 8, False), (128, 1, 24, 4, False),
+                                                   (128, 2, 8, 4, True), (256, 2, 24, 4, True)])
+def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R, batched):
     """The whole n13 K-cycle with ONE lattice cut into R y-slabs (drivers/n13_wilson_kcycle_slab.cpp, facade slab mode): setup
     (null-vector relaxation, block orthonormalisation, Galerkin build with the prolongator's halo rows) and solve on every level
     decomposed, ranks emulated by host threads.  The decomposed run draws the single-domain run's random vectors (gaussian_lattice),
     so it must FOLLOW the single-domain n13 driver (same sequential fp64 null-vector relaxation): same outer iteration count, the
     same right-hand side, the same solution norm to 1e-10, true residual below tolerance -- only the rounding of the reductions
-    (per-slab partial sums) differs."""
+    (per-slab partial sums) differs.  `batched`: the default setup instead (null vectors relaxed 8 at a time on complex<float> copies: ONE
+    halo exchange per batch apply, kernel W / kernel B with halos in fp32) -- there the single-domain driver uses the MFMA kernel where
+    the slabs use kernel B, so the two hierarchies differ by fp32 rounding: iteration counts within 1, solution norm to 1e-8."""
     import os
     import re
     import subprocess
@@ -334,7 +344,9 @@ def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R):
     subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
     gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
     args = [str(L), "-0.05", "6.0", str(levels), str(nc), gauge, "64"]
-    env = dict(os.environ, QMG_QUIET="1", QMG_NULL_BATCH="1")
+    env = dict(os.environ, QMG_QUIET="1")
+    if not batched:
+        env["QMG_NULL_BATCH"] = "1"
     plain = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle")] + args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
     one = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
     many = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
@@ -344,10 +356,13 @@ def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R):
     chk = lambda o: float(re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1))
     slab = lambda o: [float(v) for v in re.search(r"\[QMG-SLAB\]: world \d+ ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", o.stdout).groups()]
     # one rank in slab mode IS the single-domain run (its exchanges are device copies): identical to the plain driver
-    assert it(one) == it(plain) and chk(one) == chk(plain)
-    assert it(many) == it(one), (it(many), it(one))
+    if batched:
+        assert abs(it(one) - it(plain)) <= 1 and abs(it(many) - it(one)) <= 1, (it(plain), it(one), it(many))
+    else:
+        assert it(one) == it(plain) and chk(one) == chk(plain)
+        assert it(many) == it(one), (it(many), it(one))
     assert chk(many) < 1e-9
     b1, x1 = slab(one)
     bR, xR = slab(many)
-    assert abs(bR - b1) < 1e-13 * b1 and abs(xR - x1) < 1e-10 * x1, (b1, bR, x1, xR)
+    assert abs(bR - b1) < 1e-13 * b1 and abs(xR - x1) < (1e-8 if batched else 1e-10) * x1, (b1, bR, x1, xR)
     assert "world %d" % R in many.stdout
