@@ -489,7 +489,10 @@ def slab_kcycle(L, world, rank):
         subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
     fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
     try:
-        p = subprocess.run([exe, str(L), str(MASS), "6.0", "2", "8", fixture, "64"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, QMG_QUIET="1")
+        if "MASTER_PORT" in os.environ:   # its own rendezvous port (the slab_solve children used MASTER_PORT + 1 a moment ago)
+            env["QMG_COMM_PORT"] = str(int(os.environ["MASTER_PORT"]) + 2)
+        p = subprocess.run([exe, str(L), str(MASS), "6.0", "2", "8", fixture, "64"], cwd=drivers, env=env, capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return {"error": "n13_wilson_kcycle_slab timed out after 300 s on rank %d" % rank}
     if rank != 0:
