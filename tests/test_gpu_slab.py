@@ -366,3 +366,23 @@ def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R, batc
     bR, xR = slab(many)
     assert abs(bR - b1) < 1e-13 * b1 and abs(xR - x1) < (1e-8 if batched else 1e-10) * x1, (b1, bR, x1, xR)
     assert "world %d" % R in many.stdout
+
+
+def test_two_processes_on_one_device_rendezvous_and_are_refused_by_rccl_without_hanging():
+    """The launcher path with world = 2 on a one-GPU box: both processes complete the TCP rendezvous of the RCCL id (qmg_comm_init_env),
+    then RCCL refuses the second rank on the same device -- and BOTH processes must come back with an error exit in seconds, not
+    hang in a half-built communicator (this is the limit that the thread-emulated ranks work around)."""
+    import os
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", LOCAL_RANK="0", QMG_COMM_TIMEOUT_S="30")
+    args = [os.path.join(drivers, "slab_wilson_solve"), "64", "0.05", "6.0", "20", "7"]
+    t0 = time.time()
+    procs = [subprocess.Popen(args, cwd=drivers, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert time.time() - t0 < 100
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    assert all("qmg_comm_init_env failed" in o for o in outs), outs
