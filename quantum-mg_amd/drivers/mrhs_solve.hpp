@@ -22,6 +22,9 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
                                   bool quiet, int verify_mode, double setup_s, void (*print_ops_stats)(void*), void* stats_arg,
                                   QMGStencilType solve_type = QMG_MATVEC_ORIGINAL, bool f32_kcycle = false) {
   using namespace std;
+  // y-slab mode: every rank runs this in lock step on its rows; rank 0 reports
+  static std::ostream discard(nullptr);
+  std::ostream& cout = (qmg::slab().on && qmg::slab().rank != 0) ? discard : std::cout;
   if (nrhs < 1) { std::cout << "[QMG-ERROR]: nrhs must be positive\n"; return false; }
   const size_t n = (size_t)lat0->get_size_cv_l();
   {
@@ -42,9 +45,10 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
   cout << "[QMG-MRHS]: " << nrhs << " systems in lock-step batches of " << per_batch << "\n";
 
   inversion_verbose_struct verb;
-  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  const bool mute = qmg::slab().on && qmg::slab().rank != 0;
+  verb.verbosity = mute ? VERB_NONE : quiet ? VERB_SUMMARY : VERB_DETAIL;
   verb.verb_prefix = "Level 0: ";
-  verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
+  verb.precond_verbosity = (quiet || mute) ? VERB_NONE : VERB_SUMMARY;
   verb.precond_verb_prefix = "Prec ";
 
   bool ok_ = true;
@@ -62,7 +66,7 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
       qmg::BatchPool pool(n, nb);
       qmg::Batch b = pool.get(), x = pool.get(), Ax = pool.get();
       if (b.p == 0 || x.p == 0 || Ax.p == 0) { std::cout << "[QMG-ERROR]: out of device memory for a batch of " << nb << " systems\n"; return false; }
-      for (int k = 0; k < nb; k++) gaussian(b.vec(k), n, seed + (unsigned long long)(k0 + k));
+      for (int k = 0; k < nb; k++) gaussian_lattice(b.vec(k), lat0->get_dim_mu(0), lat0->get_dim_mu(1), lat0->get_nc(), seed + (unsigned long long)(k0 + k));
       if (getenv("QMG_MRHS_POINT") && k0 == 0 && nb > 1) {   // test hook: system 1 becomes a point source, which converges on its own schedule
         zero_vector(b.vec(1), n);
         qmg::set_element(b.vec(1), 5, complex<double>(1.0, 0.0));

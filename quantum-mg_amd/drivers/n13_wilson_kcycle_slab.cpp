@@ -1,6 +1,7 @@
 // n13_wilson_kcycle_slab -- the n13 K-cycle (tests/n13_wilson_kcycle/wilson_kcycle.cpp: same constants, same setup, same solve) with
 // ONE lattice cut into y-slabs over the ranks: every level of the hierarchy is decomposed.
-//   ./n13_wilson_kcycle_slab L mass beta n_refine [coarse_dof] [gauge_file] [tile]
+//   ./n13_wilson_kcycle_slab L mass beta n_refine [coarse_dof] [gauge_file] [tile] [nrhs=K [f32]]
+//   nrhs=K: K right-hand sides in lock-step batches (include/qmg/batch.hpp) on the slabs, `f32`: with the K-cycle in complex<float>
 //   ranks: one process per GPU under the launcher (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT), or
 //          QMG_COMM_EMULATE=R: R host threads of this process on one GPU (the test transport of csrc/qmg_comm.hip)
 // Nothing in the multigrid classes knows about ranks.  qmg::slab_begin() switches this thread's facade to slab mode:
@@ -15,6 +16,7 @@
 #include <thread>
 
 #include "n13_setup.hpp"
+#include "mrhs_solve.hpp"
 
 static int run(int rank, int world, int device, int argc, char** argv) {
   if (!qmg::ok(qmg_init(device), "qmg_init")) return 2;
@@ -30,6 +32,20 @@ static int run(int rank, int world, int device, int argc, char** argv) {
   StatefulMultigridMG* mg_object = s.mg_object;
   unsigned long long seed = s.seed;
   const long n = lats[0]->get_size_cv_l();
+  int nrhs = 0;
+  bool f32 = false;
+  for (int i = 8; i < argc; i++) {
+    if (std::string(argv[i]).rfind("nrhs=", 0) == 0) nrhs = atoi(argv[i] + 5);
+    if (std::string(argv[i]) == "f32") f32 = true;
+  }
+  if (nrhs > 0) {   // the lock-step batch engine on slabs: one halo exchange per batch apply, per-system reductions summed over the ranks
+    const bool ok_b = mrhs_solve_and_report(mg_object, lats[0], nrhs, seed, s.tol, s.max_iter, s.restart_freq, true, 0, s.setup_s, 0, 0, QMG_MATVEC_ORIGINAL, f32);
+    qmg_comm_all_ok(ok_b, &all);
+    s.destroy();
+    qmg::slab_end();
+    qmg_comm_finalize();
+    return all ? 0 : 1;
+  }
 
   complex<double>* b = mg_object->check_out(0);
   gaussian_lattice(b, lats[0]->get_dim_mu(0), lats[0]->get_dim_mu(1), lats[0]->get_nc(), seed++);

@@ -386,3 +386,30 @@ def test_two_processes_on_one_device_rendezvous_and_are_refused_by_rccl_without_
     assert time.time() - t0 < 100
     assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
     assert all("qmg_comm_init_env failed" in o for o in outs), outs
+
+
+@pytest.mark.parametrize("R,f32", [(4, False), (2, True)])
+def test_batched_kcycle_solve_on_slabs(R, f32):
+    """The lock-step batch engine on slabs (n13_wilson_kcycle_slab ... nrhs=4 [f32]): one halo exchange per batch apply, per-system
+    reductions summed over the ranks, the K-cycle optionally in complex<float>.  One rank in slab mode reproduces the plain batched driver
+    digit for digit; R thread-emulated ranks converge every system in the same number of iterations (+-1) to the same tolerance."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    base = ["128", "-0.05", "6.0", "2", "8", gauge, "64"]
+    tail = ["f32"] if f32 else []
+    env = dict(os.environ, QMG_QUIET="1")
+    plain = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_mrhs")] + base + ["4"] + tail, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + base + ["nrhs=4"] + tail, cwd=drivers, env=dict(env, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + base + ["nrhs=4"] + tail, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    pat = r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([\d.e+-]+) ; check tolerance ([\d.e+-]+)"
+    rows_ = [re.findall(pat, o.stdout) for o in (plain, one, many)]
+    for o, r in zip((plain, one, many), rows_):
+        assert o.returncode == 0 and len(r) == 4, o.stdout[-2000:] + o.stderr[-1000:]
+    assert rows_[0] == rows_[1]                                                    # one slab = the whole lattice: the same run
+    for a, b in zip(rows_[1], rows_[2]):
+        assert abs(int(a[1]) - int(b[1])) <= 1 and float(b[3]) < 1e-9, (a, b)
