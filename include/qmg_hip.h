@@ -312,6 +312,10 @@ int qmg_comm_finalize(void);
 #define QMG_SLAB_H16 0x100   /* or-ed into the storage argument: matrices stored as complex<half> (vectors QMG_C32) */
 int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly_local, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
                       size_t halo_stride, void* stream);
+/* rows of one parity only (parities: bit 0 even sites' rows, bit 1 odd sites' rows): what a D_eo / D_oe piece reads; the vectors of the
+ * even-odd Schur systems are half-length, the other parity's rows do not exist */
+int qmg_halo_exchange_parity(int dtype, const void* vec, int Lx, int Ly_local, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
+                             size_t halo_stride, unsigned parities, void* stream);
 int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi,
                            unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows, void* stream);
 int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, double wilson_coeff,
@@ -322,6 +326,8 @@ int qmg_comm_set_distributed_reductions(int on);
 int qmg_coarse_build_slab(void* cclover, void* chopping, const qmg_stencil_desc* fine, const void* nullvecs, const void* restrict_vecs, int cLx, int cLy, int cnc,
                           const void* P_halo_lo, const void* P_halo_hi, size_t halo_stride, void* stream);
 int qmg_gaussian_slab(void* x, int Lx, int Ly_global, int y0, int Ly_local, int nc, unsigned long long seed, void* stream);
+/* right-block-Jacobi hopping on a slab: after qmg_build_rbjacobi(cinv, rb_clover, NULL, d) and a halo exchange of cinv (nc^2 components) */
+int qmg_rb_hopping_slab(void* rb_hopping, const qmg_stencil_desc* d, const void* cinv, const void* cinv_halo_lo, const void* cinv_halo_hi, void* stream);
 /* Test transport: `world` host threads of one process act as ranks on one GPU (device copies + host sums behind thread barriers),
  * because one-GPU boxes cannot run two RCCL ranks.  Everything above the transport is the code the RCCL path runs. */
 int qmg_comm_emulate_begin(int world);

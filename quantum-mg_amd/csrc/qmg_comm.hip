@@ -338,6 +338,15 @@ int qmg_comm_set_distributed_reductions(int on) {
 // single-domain kernels do by index.  Asynchronous on `stream`.
 int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
                       size_t halo_stride, void* stream) {
+  return qmg_halo_exchange_parity(dtype, vec, Lx, Ly, nc, halo_lo, halo_hi, nrhs, vec_stride, halo_stride, 3u, stream);
+}
+
+// The same for the rows of ONE parity only (parities: bit 0 = even sites' rows, bit 1 = odd sites' rows).  An even-odd operator piece
+// reads one parity of its right-hand side: D_eo the odd rows, D_oe the even rows -- and the Schur systems' vectors are HALF-length
+// (only the even half exists), so the other parity's rows must not even be addressed.
+int qmg_halo_exchange_parity(int dtype, const void* vec, int Lx, int Ly, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
+                             size_t halo_stride, unsigned parities, void* stream) {
+  if (!(parities & 3u)) return QMG_SUCCESS;
   if (!valid_dtype(dtype) || !vec || !halo_lo || !halo_hi || !valid_lattice(Lx, Ly) || nc < 1 || nrhs < 1) return QMG_ERR_INVALID;
   const size_t esz = dtype_size(dtype);
   const size_t row = (size_t)(Lx / 2) * nc;                 // complex elements of one parity's row
@@ -353,6 +362,7 @@ int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* 
     int erc = QMG_SUCCESS;
     for (int k = 0; k < nrhs && erc == QMG_SUCCESS; k++)
       for (int q = 0; q < 2; q++) {
+        if (!((parities >> q) & 1u)) continue;
         const char* vdn = (const char*)g_tw.vec[down] + (size_t)k * vec_stride * esz;   // down's LAST row is my row -1
         const char* vup = (const char*)g_tw.vec[up] + (size_t)k * vec_stride * esz;     // up's FIRST row is my row Ly
         char* lo = (char*)halo_lo + ((size_t)k * halo_stride + (size_t)q * row) * esz;
@@ -372,6 +382,7 @@ int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly, int nc, void* 
     char* lo = (char*)halo_lo + (size_t)k * halo_stride * esz;
     char* hi = (char*)halo_hi + (size_t)k * halo_stride * esz;
     for (int q = 0; q < 2; q++) {
+      if (!((parities >> q) & 1u)) continue;
       const char* first = v + ((size_t)q * half) * esz;                       // row y = 0 of parity q
       const char* last = v + ((size_t)q * half + (size_t)(Ly - 1) * row) * esz;  // row y = Ly - 1
       if (rccl) {

@@ -227,8 +227,10 @@ __global__ __launch_bounds__(BLOCK) void k_clover_inverse(cplx* __restrict__ cin
 }
 
 // rb_hopping[dir](x) = hopping[dir](x) . cinv(x + dir)   (:1556-1581)
+// (y-slab: cinv of rows -1 / Ly from ci_lo / ci_hi, [parity][hr][nc^2], filled by qmg_halo_exchange of cinv as an nc^2-component field)
 __global__ __launch_bounds__(BLOCK) void k_rb_hopping(cplx* __restrict__ rb, const cplx* __restrict__ hop,
-                                                      const cplx* __restrict__ cinv, int nc, int hr, int Ly) {
+                                                      const cplx* __restrict__ cinv, int nc, int hr, int Ly,
+                                                      const cplx* __restrict__ ci_lo, const cplx* __restrict__ ci_hi) {
   const long half_vol = (long)hr * Ly, vol = 2 * half_vol;
   const long nc2 = (long)nc * nc, cm = vol * nc2;
   const long total = 4 * cm;
@@ -245,6 +247,8 @@ __global__ __launch_bounds__(BLOCK) void k_rb_hopping(cplx* __restrict__ rb, con
     const long nb = neighbour_site(cdir, p, y, j, hr, Ly, half_vol);
     const cplx* hrow = hop + (long)dir * cm + site * nc2 + (long)r * nc;
     const cplx* ci = cinv + nb * nc2 + c;
+    if (dir == 1 && ci_hi && y + 1 == Ly) ci = ci_hi + ((long)(1 - p) * hr + j) * nc2 + c;   // the +y neighbour lives on the next rank
+    if (dir == 3 && ci_lo && y == 0) ci = ci_lo + ((long)(1 - p) * hr + j) * nc2 + c;
     cplx acc = cmake(0.0, 0.0);
     for (int k = 0; k < nc; k++) cmac(acc, hrow[k], ci[(long)k * nc]);
     rb[t] = acc;
@@ -401,9 +405,21 @@ int qmg_build_rbjacobi(void* cinv, void* rb_clover, void* rb_hopping, const qmg_
   }
   if (d->hopping && rb_hopping) {
     k_rb_hopping<<<grid_1d((size_t)4 * vol * nc * nc), BLOCK, 0, st>>>((cplx*)rb_hopping, (const cplx*)d->hopping, (const cplx*)cinv,
-                                                                      nc, d->Lx / 2, d->Ly);
+                                                                      nc, d->Lx / 2, d->Ly, nullptr, nullptr);
     QMG_LAUNCH_CHECK();
   }
+  return QMG_SUCCESS;
+}
+
+// The hopping part of the right-block-Jacobi stencil on a y-slab: rb_hopping[dir](x) = hopping[dir](x) . cinv(x + dir) with cinv of the
+// rows -1 / Ly from the halo buffers.  Sequence on a slab: qmg_build_rbjacobi(cinv, rb_clover, NULL, d) -- cinv and the identity clover
+// are site-local --, qmg_halo_exchange of cinv as a field with nc^2 components per site, then this.
+int qmg_rb_hopping_slab(void* rb_hopping, const qmg_stencil_desc* d, const void* cinv, const void* cinv_halo_lo, const void* cinv_halo_hi, void* stream) {
+  if (!rb_hopping || !d || !d->hopping || !cinv || !cinv_halo_lo || !cinv_halo_hi || !valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
+  const long vol = (long)d->Lx * d->Ly;
+  k_rb_hopping<<<grid_1d((size_t)4 * vol * d->nc * d->nc), BLOCK, 0, as_stream(stream)>>>((cplx*)rb_hopping, (const cplx*)d->hopping, (const cplx*)cinv, d->nc,
+                                                                                            d->Lx / 2, d->Ly, (const cplx*)cinv_halo_lo, (const cplx*)cinv_halo_hi);
+  QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
 

@@ -330,7 +330,11 @@ int qmg_stencil_apply_h16(const qmg_stencil_desc* d, void* lhs, const void* rhs,
 // fp64 or fp32, rows = 0 (QMG_ERR_UNSUPPORTED otherwise).
 int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi,
                            unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows, void* stream) {
-  if (!d || !lhs || !rhs || !halo_lo || !halo_hi || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2 || lhs == rhs) return QMG_ERR_INVALID;
+  if (!d || !lhs || !rhs || !halo_lo || !halo_hi || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2) return QMG_ERR_INVALID;
+  if (lhs == rhs) {   // in place only for the reference's aliased use (stencil_2d.h:1904): ONE parity written, from hops alone
+    const unsigned ev = pieces & (QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E), od = pieces & (QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O);
+    if ((ev && od) || (pieces & (QMG_P_CLOVER | QMG_P_SHIFT))) return QMG_ERR_INVALID;
+  }
   if (!valid_lattice(d->Lx, d->Ly)) return QMG_ERR_INVALID;
   const bool h16 = storage & QMG_SLAB_H16;
   const int dtype = storage & ~QMG_SLAB_H16;

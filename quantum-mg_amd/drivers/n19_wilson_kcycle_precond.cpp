@@ -4,7 +4,10 @@
 // (solve_type = QMG_MATVEC_RIGHT_SCHUR, n19:107), the coarse operators are Galerkin-coarsened from the
 // rbjacobi stencil (n19:171, coarse.h:120-123) and get their own rbjacobi variant
 // (QMG_COARSE_BUILD_RBJACOBI, n19:290).
-//   ./n19_wilson_kcycle_precond [L=128] [n_refine=3] [gauge_file] [tile]
+//   ./n19_wilson_kcycle_precond [L=128] [n_refine=3] [gauge_file] [tile] [nrhs=K]
+//   QMG_SLAB=1 (one process per GPU under a launcher, or QMG_COMM_EMULATE=R host threads on one GPU): the same run with ONE lattice cut
+//   into y-slabs on every level (facade slab mode, include/qmg/qmg_device.hpp) -- the rbjacobi builds exchange the halo rows
+//   of cinv, the Galerkin builds those of the prolongator, every apply those of its right-hand side.
 // Constants as n19:50-107: mass -0.07, 4x4 blocks, coarse_dof 8, outer tol 1e-8 / 1000 / restart 32,
 // inner and coarsest 0.2 / 1000 / 32, 2+2 MR smoothing; null vectors: 4 gaussian vectors relaxed on the
 // rbjacobi residual equation by GCR(64), 500 its, 5e-5 (n19:222), chirally doubled.
@@ -14,20 +17,28 @@
 #include <iomanip>
 #include <iostream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../include/qmg/qmg.hpp"
 #include "mrhs_solve.hpp"
 
 using namespace std;
 
-int main(int argc, char** argv) {
+static int run(int rank, int world, int device, bool slab_mode, int argc, char** argv) {
+  if (!qmg::ok(qmg_init(device), "qmg_init")) return 2;
+  if (slab_mode) {
+    if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env") || !qmg::slab_begin()) return 2;
+  }
+  const bool root = rank == 0;
+  static std::ostream discard(nullptr);
+  std::ostream& cout = root ? std::cout : discard;
   cout << setprecision(20);
-  if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
   const int x_len = (argc > 1) ? stoi(argv[1]) : 128, y_len = x_len;
   const int n_refine = (argc > 2) ? stoi(argv[2]) : 3;
   const string gauge_file = (argc > 3) ? argv[3] : "../../tests/golden/l128t128b60_heatbath.dat";
   const int tile = (argc > 4) ? stoi(argv[4]) : x_len;
-  const bool quiet = getenv("QMG_QUIET") != 0;
+  const bool quiet = getenv("QMG_QUIET") != 0 || !root;
   const int dof = Wilson2D::get_dof();
   const double mass = -0.07;
   const int x_block = 4, y_block = 4, coarse_dof = 8;
@@ -41,14 +52,22 @@ int main(int argc, char** argv) {
 
   inversion_info invif;
   inversion_verbose_struct verb;
-  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verbosity = !root ? VERB_NONE : quiet ? VERB_SUMMARY : VERB_DETAIL;
   verb.verb_prefix = "Level 0: ";
   verb.precond_verbosity = quiet ? VERB_NONE : VERB_SUMMARY;
   verb.precond_verb_prefix = "Prec ";
   inversion_verbose_struct verb_null(VERB_NONE, "");
 
+  // slab mode: this rank's rows of every level (whole, even block rows down to the coarsest level)
+  int y_loc = y_len / world;
+  {
+    int rows = y_loc;
+    bool fits = (y_len % world == 0) && !(rows & 1);
+    for (int i = 0; i < n_refine && fits; i++) { fits = (rows % y_block == 0); rows /= y_block; fits = fits && !(rows & 1) && rows >= 2; }
+    if (!fits) { cout << "[QMG-ERROR]: " << y_len << " rows do not split into " << world << " slabs of whole, even block rows on every level.\n"; return 4; }
+  }
   Lattice2D** lats = new Lattice2D*[n_refine + 1];
-  lats[0] = new Lattice2D(x_len, y_len, dof);
+  lats[0] = new Lattice2D(x_len, y_loc, dof);
   Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
   complex<double>* gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
   bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
@@ -67,7 +86,7 @@ int main(int argc, char** argv) {
   StatefulMultigridMG* mg_object = new StatefulMultigridMG(lats[0], wilson_op, coarsest_solve_obj);
   const MultigridMG::QMGMultigridPrecondStencil stencil_to_coarsen = MultigridMG::QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI;
 
-  int curr_x_len = x_len, curr_y_len = y_len;
+  int curr_x_len = x_len, curr_y_len = y_loc;
   TransferMG** transfer_objs = new TransferMG*[n_refine];
   for (int i = 1; i <= n_refine; i++) {
     curr_x_len /= x_block; curr_y_len /= y_block;
@@ -78,7 +97,7 @@ int main(int argc, char** argv) {
       null_vectors[j] = allocate_vector<complex<double>>(fsize);
       zero_vector(null_vectors[j], fsize);
       complex<double>* rand_guess = mg_object->get_storage(i - 1)->check_out();
-      gaussian(rand_guess, fsize, seed++);
+      gaussian_lattice(rand_guess, lats[i - 1]->get_dim_mu(0), lats[i - 1]->get_dim_mu(1), lats[i - 1]->get_nc(), seed++);
       for (int k = 0; k < j; k++) orthogonal(rand_guess, null_vectors[k], fsize);
       complex<double>* Arand_guess = mg_object->get_storage(i - 1)->check_out();
       zero_vector(Arand_guess, fsize);
@@ -117,7 +136,7 @@ int main(int argc, char** argv) {
   const int solve_size = lats[0]->get_size_cv() / 2;
 
   complex<double>* b = mg_object->check_out(0);
-  gaussian(b, lats[0]->get_size_cv_l(), seed++);
+  gaussian_lattice(b, lats[0]->get_dim_mu(0), lats[0]->get_dim_mu(1), lats[0]->get_nc(), seed++);
   const double bnorm = sqrt(norm2sq(b, lats[0]->get_size_cv_l()));
   complex<double>* x = mg_object->check_out(0);
   zero_vector(x, lats[0]->get_size_cv_l());
@@ -130,7 +149,7 @@ int main(int argc, char** argv) {
   auto t0 = std::chrono::steady_clock::now();
   invif = minv_vector_gcr_var_precond_restart(x, b_prep, solve_size, max_iter, tol, restart_freq, apply_stencil_op, (void*)mg_object->get_stencil(0),
                                               StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
-  qmg_stream_sync(0);
+  qmg_stream_sync(qmg::current_stream());
   const double solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   cout << "Multigrid " << (invif.success ? "converged" : "failed to converge") << " in " << invif.iter << " iterations with alleged tolerance "
        << sqrt(invif.resSq) / bnorm << ".\n";
@@ -142,6 +161,7 @@ int main(int argc, char** argv) {
   mg_object->apply_stencil(Ax, x_reconstruct, 0);   // the ORIGINAL operator
   const double true_res = sqrt(diffnorm2sq(b, Ax, lats[0]->get_size_cv_l())) / bnorm;
   cout << "Check tolerance " << true_res << "\n";
+  if (slab_mode) { const double xn = norm2sq(x_reconstruct, lats[0]->get_size_cv_l()); cout << setprecision(15) << "[QMG-SLAB]: world " << world << " ; |b| " << bnorm << " ; |x|^2 " << xn << "\n" << setprecision(20); }
   cout << setprecision(6) << "[QMG-TIMING]: solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
   mg_object->check_in(b_prep, 0); mg_object->check_in(x_reconstruct, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
 
@@ -160,5 +180,40 @@ int main(int argc, char** argv) {
   delete[] lats;
   deallocate_vector(&gauge_field);
   qmg::VecPool::release_all();
+  if (slab_mode) {
+    int all = 0;
+    qmg_comm_all_ok(ok_, &all);
+    ok_ = all != 0;
+    qmg::slab_end();
+    qmg_comm_finalize();
+  }
   return ok_ ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
+  if (emulate > 0) {   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
+    std::vector<int> rc(emulate, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < emulate; r++)
+      th.emplace_back([&, r] {
+        qmg_comm_emulate_attach(r);
+        void* st = 0;
+        qmg_stream_create(&st);
+        qmg::current_stream() = st;
+        rc[r] = run(r, emulate, 0, true, argc, argv);
+        qmg_stream_sync(st);
+        qmg::current_stream() = 0;
+        qmg_stream_destroy(st);
+      });
+    for (auto& t : th) t.join();
+    qmg_comm_emulate_end();
+    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
+    return 0;
+  }
+  const bool slab_mode = getenv("QMG_SLAB") != 0;
+  const int rank = (slab_mode && getenv("RANK")) ? atoi(getenv("RANK")) : 0;
+  const int world = (slab_mode && getenv("WORLD_SIZE")) ? atoi(getenv("WORLD_SIZE")) : 1;
+  return run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, slab_mode, argc, argv);
 }

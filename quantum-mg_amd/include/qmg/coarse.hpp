@@ -70,7 +70,6 @@ struct CoarseOperator2D : public Stencil2D {
       const int nv = lat->get_nc();
       const size_t hs = (size_t)fd.Lx * fd.nc;
       complex<double>*lo = allocate_vector<complex<double>>(hs * nv), *hi = allocate_vector<complex<double>>(hs * nv);
-      if (use_rbjacobi) std::cout << "[QMG-ERROR]: Galerkin builds from the right-block-Jacobi stencil are not decomposed into slabs yet.\n";
       qmg::ok(qmg_halo_exchange(QMG_C64, transfer->device_null_vectors(), fd.Lx, fd.Ly, fd.nc, lo, hi, nv, (size_t)fine_lattice->get_size_cv_l(), hs, qmg::current_stream()),
               "qmg_halo_exchange");
       qmg::ok(qmg_coarse_build_slab(clover, hopping, &fd, transfer->device_null_vectors(), transfer->device_restrict_vectors(), lat->get_dim_mu(0), lat->get_dim_mu(1),

@@ -125,12 +125,15 @@ struct Stencil2D {
     if (!slab_halo_hi) slab_halo_hi = allocate_vector<complex<double>>((size_t)16 * lat->get_dim_mu(0) * lat->get_nc());
     return slab_halo_lo && slab_halo_hi;
   }
+  // which parities of the right-hand side the hops of `pieces` read: D_eo (even sites written) reads odd rows, D_oe even rows
+  static unsigned halo_parities(unsigned pieces) { return ((pieces & QMG_P_EO) ? 2u : 0u) | ((pieces & QMG_P_OE) ? 1u : 0u); }
   // one system on a slab: exchange the halo rows of rhs with the neighbouring ranks, then apply with them
   void launch_slab(const qmg_stencil_desc& d, unsigned pieces, complex<double>* lhs, complex<double>* rhs, bool original_arrays) {
     if (!slab_halos()) { std::cout << "[QMG-ERROR]: no memory for the halo rows\n"; return; }
     const size_t hs = (size_t)d.Lx * d.nc;
     void* st = qmg::current_stream();
-    if (!qmg::ok(qmg_halo_exchange(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, st), "qmg_halo_exchange")) return;
+    if (!qmg::ok(qmg_halo_exchange_parity(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, d.hopping || original_arrays ? halo_parities(pieces) : 0u, st),
+                 "qmg_halo_exchange")) return;
     if (original_arrays && direct.on) {   // Wilson straight from the (global, replicated) links
       const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs, slab_halo_lo,
                                              slab_halo_hi, pieces, 1, 0, hs, 1u, 0, st);
@@ -422,7 +425,7 @@ struct Stencil2D {
       if (nrhs > 16 || !slab_halos()) { std::cout << "[QMG-ERROR]: a slab batch is at most 16 systems\n"; return; }
       const size_t hs = (size_t)d.Lx * d.nc;
       void* st = qmg::current_stream();
-      if (!qmg::ok(qmg_halo_exchange(dt, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, nrhs, stride, hs, st), "qmg_halo_exchange")) return;
+      if (!qmg::ok(qmg_halo_exchange_parity(dt, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, nrhs, stride, hs, halo_parities(pieces), st), "qmg_halo_exchange")) return;
       if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (!f || direct.gauge32)) {
         const int rc = qmg_wilson_apply_direct(dt, &d, f ? direct.gauge32 : (void*)direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs,
                                                slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st);
@@ -610,6 +613,15 @@ struct Stencil2D {
     rbjacobi_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
     if (hopping != 0) rbjacobi_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
     qmg_stencil_desc d = desc();
+    if (qmg::slab().on && rbjacobi_hopping) {   // cinv is site-local; the hops across the slab boundary need the neighbouring ranks' cinv rows
+      const size_t hs = (size_t)d.Lx * d.nc * d.nc;
+      complex<double>*lo = allocate_vector<complex<double>>(hs), *hi = allocate_vector<complex<double>>(hs);
+      qmg::ok(qmg_build_rbjacobi(rbjacobi_cinv, rbjacobi_clover, 0, &d, qmg::current_stream()), "qmg_build_rbjacobi");
+      qmg::ok(qmg_halo_exchange(QMG_C64, rbjacobi_cinv, d.Lx, d.Ly, d.nc * d.nc, lo, hi, 1, 0, hs, qmg::current_stream()), "qmg_halo_exchange");
+      qmg::ok(qmg_rb_hopping_slab(rbjacobi_hopping, &d, rbjacobi_cinv, lo, hi, qmg::current_stream()), "qmg_rb_hopping_slab");
+      qmg::ok(qmg_stream_sync(qmg::current_stream()), "qmg_stream_sync");
+      deallocate_vector(&lo); deallocate_vector(&hi);
+    } else
     qmg::ok(qmg_build_rbjacobi(rbjacobi_cinv, rbjacobi_clover, rbjacobi_hopping, &d, qmg::current_stream()), "qmg_build_rbjacobi");
     if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
     if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";

@@ -413,3 +413,34 @@ def test_batched_kcycle_solve_on_slabs(R, f32):
     assert rows_[0] == rows_[1]                                                    # one slab = the whole lattice: the same run
     for a, b in zip(rows_[1], rows_[2]):
         assert abs(int(a[1]) - int(b[1])) <= 1 and float(b[3]) < 1e-9, (a, b)
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_schur_kcycle_on_slabs(R):
+    """The red-black form on slabs (n19: every level solved as the even-odd Schur complement of its right-block-Jacobi operator, coarse
+    operators Galerkin-coarsened from the rbjacobi stencil): the rbjacobi builds exchange the halo rows of cinv (qmg_rb_hopping_slab),
+    the applies only the rows of the parity they read (qmg_halo_exchange_parity: the Schur systems' vectors are half-length), the in-place
+    D_eo of the Schur apply runs through the slab kernels.  One rank in slab mode = the plain n19 driver digit for digit; R thread
+    ranks: the same 11 iterations, the same solution norm to 1e-11, and the batched Schur solve converges every system alike."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l128t128b60_heatbath.dat")
+    args = [os.path.join(drivers, "n19_wilson_kcycle_precond"), "128", "2", gauge, "128", "nrhs=2"]
+    env = dict(os.environ, QMG_QUIET="1")
+    plain = subprocess.run(args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run(args, cwd=drivers, env=dict(env, QMG_SLAB="1", RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run(args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    for o in (plain, one, many):
+        assert o.returncode == 0, o.stdout[-2500:] + o.stderr[-1500:]
+    it = lambda o: int(re.search(r"Multigrid converged in (\d+) iterations", o.stdout).group(1))
+    chk = lambda o: re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1)
+    xn = lambda o: float(re.search(r"\|x\|\^2 ([\d.e+-]+)", o.stdout).group(1))
+    assert it(one) == it(plain) and chk(one) == chk(plain)
+    assert it(many) == it(one) and float(chk(many)) < 1e-7
+    assert abs(xn(many) - xn(one)) < 1e-11 * xn(one)
+    pat = r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations"
+    assert re.findall(pat, many.stdout) == re.findall(pat, plain.stdout) and len(re.findall(pat, many.stdout)) == 2
