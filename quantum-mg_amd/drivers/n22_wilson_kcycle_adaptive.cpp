@@ -38,9 +38,17 @@
 #include "../include/qmg/qmg.hpp"
 #include "mrhs_solve.hpp"
 
+#include <vector>
+
 using namespace std;
 
-static unsigned long long g_seed = 1337ull;
+// per host thread (QMG_COMM_EMULATE: the ranks of a slab run are threads): the seed counter, and whether this rank reports
+static thread_local unsigned long long g_seed = 1337ull;
+static thread_local bool t_root = true;
+static std::ostream& qout() { static std::ostream discard(nullptr); return t_root ? std::cout : discard; }
+#define cout qout()
+// a Gaussian vector on a level's lattice (slab mode: the slab's rows of the single-domain run's vector)
+static void gaussian_on(Lattice2D* lat, complex<double>* v, unsigned long long seed) { gaussian_lattice(v, lat->get_dim_mu(0), lat->get_dim_mu(1), lat->get_nc(), seed); }
 
 struct Setup {
   StatefulMultigridMG* mg;
@@ -69,7 +77,7 @@ static TransferMG* build_coarse_by_restrict(Setup& s, int fine_level, Lattice2D*
     zero_vector(null_vectors[j], n);
     zero_vector(null_vectors[j + coarse_dof / 2], n);
     complex<double>* temp_rand = mg->get_storage(fine_idx)->check_out();
-    gaussian(temp_rand, n, g_seed++);
+    gaussian_on(mg->get_lattice(fine_idx), temp_rand, g_seed++);
     inversion_info invif = minv_vector_richardson(s.test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, 0.33, 250, apply_stencil_2D_M,
                                                   (void*)mg->get_stencil(fine_idx), &verb);
     mg->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count, fine_idx);
@@ -93,22 +101,23 @@ static TransferMG* build_coarse_by_restrict(Setup& s, int fine_level, Lattice2D*
   return transfer_obj;
 }
 
-int main(int argc, char** argv) {
-  if (argc < 6) {
-    std::cout << "Error: ./wilson_kcycle expects five arguments, L, mass, beta, n_refine, n_setup. Try mass = -0.075 for beta 6.0.\n";
-    return -1;
-  }
+// slab_mode (QMG_SLAB=1 under a launcher, or QMG_COMM_EMULATE=R threads): ONE lattice cut into y-slabs on every level; every rank
+// takes part in every relaxation and in the one solve (facade slab mode).  Otherwise the ranks hold replicas and shard the work.
+static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, int argc, char** argv) {
+  g_seed = 1337ull;
+  t_root = !slab_mode || proc_rank == 0;
   cout << setprecision(20);
-  const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
-  const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
-  const int local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
   if (!qmg::ok(qmg_init(local_rank), "qmg_init")) return 2;
-  const bool use_comm = world > 1 || getenv("QMG_COMM_FORCE_RCCL") != 0;
-  if (use_comm) {   // the RCCL id comes through the launcher's rendezvous (QMG_COMM_ID_HEX or one TCP exchange with rank 0; bounded waits)
+  // the rank / world the SHARDING logic below sees: in slab mode nothing is sharded by rank
+  const int world = slab_mode ? 1 : proc_world, rank = slab_mode ? 0 : proc_rank;
+  const bool use_comm = !slab_mode && (world > 1 || getenv("QMG_COMM_FORCE_RCCL") != 0);
+  if (slab_mode) {
+    if (!qmg::ok(qmg_comm_init_env(proc_world, proc_rank), "qmg_comm_init_env") || !qmg::slab_begin()) return 2;
+  } else if (use_comm) {   // the RCCL id comes through the launcher's rendezvous (QMG_COMM_ID_HEX or one TCP exchange with rank 0; bounded waits)
     if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env")) return 2;
     cout << "[QMG-INFO]: rank " << rank << " of " << world << " on device " << local_rank << "\n";
   }
-  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
+  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
   const int x_len = stoi(argv[1]), y_len = x_len;
   const double mass = stod(argv[2]);
   const int n_refine = stoi(argv[4]);
@@ -124,10 +133,10 @@ int main(int argc, char** argv) {
     if (o == "schur") schur = true;
     else if (o == "f32") f32 = true;
     else if (o.rfind("nrhs=", 0) == 0) nrhs_batched = stoi(o.substr(5));
-    else { std::cout << "Error: unknown option " << o << "\n"; return -1; }
+    else { cout << "Error: unknown option " << o << "\n"; return -1; }
   }
   if (f32 && nrhs_batched == 0) nrhs_batched = 1;
-  const bool quiet = getenv("QMG_QUIET") != 0;
+  const bool quiet = getenv("QMG_QUIET") != 0 || !t_root;
   const int dof = Wilson2D::get_dof();
   const int x_block = 4, y_block = 4, coarse_dof = 8;
   const double tol = 1e-10; const int max_iter = 1000; const int restart_freq = 64;
@@ -144,8 +153,17 @@ int main(int argc, char** argv) {
   verb.precond_verbosity = VERB_NONE;
   verb.precond_verb_prefix = "Prec ";
 
+  // slab mode: this rank's rows of every level (whole, even block rows down to the coarsest level)
+  const int slabs = slab_mode ? proc_world : 1;
+  const int y_loc = y_len / slabs;
+  {
+    int rows = y_loc;
+    bool fits = (y_len % slabs == 0) && !(rows & 1);
+    for (int i = 0; i < n_refine && fits; i++) { fits = (rows % y_block == 0); rows /= y_block; fits = fits && !(rows & 1) && rows >= 2; }
+    if (!fits) { cout << "[QMG-ERROR]: " << y_len << " rows do not split into " << slabs << " slabs of whole, even block rows on every level.\n"; return 4; }
+  }
   Lattice2D** lats = new Lattice2D*[n_refine + 1];
-  lats[0] = new Lattice2D(x_len, y_len, dof);
+  lats[0] = new Lattice2D(x_len, y_loc, dof);
   Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
   complex<double>* gauge_field = allocate_vector<complex<double>>(lat_gauge->get_size_gauge());
   bool got = (x_len == tile) ? read_gauge_u1(gauge_field, lat_gauge, gauge_file) : read_gauge_u1_tiled(gauge_field, lat_gauge, gauge_file, tile);
@@ -166,7 +184,7 @@ int main(int argc, char** argv) {
   StatefulMultigridMG::LevelSolveMG** level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
   TransferMG** transfer_objs = new TransferMG*[n_refine];
   complex<double>*** test_vectors = new complex<double>**[n_refine];
-  int cx = x_len, cy = y_len;
+  int cx = x_len, cy = y_loc;
   for (int i = 1; i <= n_refine; i++) {
     const int fine_idx = i - 1;
     cx /= x_block; cy /= y_block;
@@ -200,7 +218,7 @@ int main(int argc, char** argv) {
       zero_vector(null_vectors[j], n);
       zero_vector(null_vectors[j + coarse_dof / 2], n);
       complex<double>* temp_rand = mg_object->get_storage(fine_idx)->check_out();
-      gaussian(temp_rand, n, g_seed++);
+      gaussian_on(lats[fine_idx], temp_rand, g_seed++);
       invif = minv_vector_richardson(test_vectors[fine_idx][j], temp_rand, (int)n, 10, 1e-10, 0.33, 250, apply_stencil_2D_M, (void*)mg_object->get_stencil(fine_idx), &verb);
       mg_object->add_tracker_count(QMG_DSLASH_TYPE_NULLVEC, invif.ops_count, fine_idx);
       mg_object->get_storage(fine_idx)->check_in(temp_rand);
@@ -307,13 +325,13 @@ int main(int argc, char** argv) {
     level_solve_objs[i]->intermediate_iters = inner_max_iter;
     level_solve_objs[i]->intermediate_restart_freq = inner_restart_freq;
   }
-  qmg_stream_sync(0);
+  qmg_stream_sync(qmg::current_stream());
   const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
 
   const long n0 = lats[0]->get_size_cv_l();
   complex<double>* b = mg_object->check_out(0);
   g_seed += (unsigned long long)rank;   // independent right-hand sides: one per rank
-  gaussian(b, n0, g_seed++);
+  gaussian_on(lats[0], b, g_seed++);
   const double bnorm = sqrt(norm2sq(b, n0));
   complex<double>* x = mg_object->check_out(0);
   zero_vector(x, n0);
@@ -328,18 +346,18 @@ int main(int argc, char** argv) {
   auto t0 = std::chrono::steady_clock::now();
   invif = minv_vector_gcr_var_precond_restart(x, b_prep, solve_size, max_iter, tol, restart_freq, Stencil2D::get_apply_function(solve_type),
                                               (void*)mg_object->get_stencil(0), StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
-  qmg_stream_sync(0);
+  qmg_stream_sync(qmg::current_stream());
   const double solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   mg_object->add_tracker_count(QMG_DSLASH_TYPE_KRYLOV, invif.ops_count, 0);
   mg_object->add_iterations_count(invif.iter, 0);
   cout << "Multigrid " << (invif.success ? "converged" : "failed to converge") << " in " << invif.iter << " iterations with alleged tolerance "
        << sqrt(invif.resSq) / bnorm << ".\n";
   for (int i = 0; i < n_refine + 1; i++)
-    std::cout << "[QMG-OPS-STATS]: Level " << i << " NullVec " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_NULLVEC, i) << " PreSmooth "
+    cout << "[QMG-OPS-STATS]: Level " << i << " NullVec " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_NULLVEC, i) << " PreSmooth "
               << mg_object->get_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, i) << " Krylov " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_KRYLOV, i)
               << " PostSmooth " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, i) << " Total " << mg_object->get_total_count(i) << "\n";
   std::vector<double> avg_iter = mg_object->query_average_iterations();
-  for (int i = 0; i < n_refine + 1; i++) std::cout << "[QMG-ITER-STATS]: Level " << i << " AverageIters " << avg_iter[i] << "\n";
+  for (int i = 0; i < n_refine + 1; i++) cout << "[QMG-ITER-STATS]: Level " << i << " AverageIters " << avg_iter[i] << "\n";
   complex<double>* x_rec = mg_object->check_out(0);
   zero_vector(x_rec, n0);
   mg_object->get_stencil(0)->reconstruct_M(x_rec, x, b, solve_type);
@@ -347,6 +365,7 @@ int main(int argc, char** argv) {
   mg_object->apply_stencil(Ax, x_rec, 0);
   const double true_res = sqrt(diffnorm2sq(b, Ax, n0)) / bnorm;
   cout << "Check tolerance " << true_res << "\n";
+  if (slab_mode) { const double xn = norm2sq(x_rec, n0); cout << setprecision(15) << "[QMG-SLAB]: world " << proc_world << " ; |b| " << bnorm << " ; |x|^2 " << xn << "\n" << setprecision(20); }
   cout << setprecision(6) << "[QMG-TIMING]: setup " << setup_s << " s ; solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
   mg_object->check_in(x_rec, 0); mg_object->check_in(b_prep, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
 
@@ -365,6 +384,43 @@ int main(int argc, char** argv) {
   delete[] lats;
   deallocate_vector(&gauge_field);
   qmg::VecPool::release_all();
-  if (use_comm) qmg_comm_finalize();
+  if (slab_mode) {
+    int all = 0;
+    qmg_comm_all_ok(ok_, &all);
+    ok_ = all != 0;
+    qmg::slab_end();
+    qmg_comm_finalize();
+  } else if (use_comm) qmg_comm_finalize();
   return ok_ ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    cout << "Error: ./wilson_kcycle expects five arguments, L, mass, beta, n_refine, n_setup. Try mass = -0.075 for beta 6.0.\n";
+    return -1;
+  }
+  const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
+  if (emulate > 0) {   // R slab ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
+    std::vector<int> rc(emulate, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < emulate; r++)
+      th.emplace_back([&, r] {
+        qmg_comm_emulate_attach(r);
+        void* st = 0;
+        qmg_stream_create(&st);
+        qmg::current_stream() = st;
+        rc[r] = run(r, emulate, 0, true, argc, argv);
+        qmg_stream_sync(st);
+        qmg::current_stream() = 0;
+        qmg_stream_destroy(st);
+      });
+    for (auto& t : th) t.join();
+    qmg_comm_emulate_end();
+    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
+    return 0;
+  }
+  const bool slab_mode = getenv("QMG_SLAB") != 0;
+  return run(getenv("RANK") ? atoi(getenv("RANK")) : 0, getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0,
+             slab_mode, argc, argv);
 }

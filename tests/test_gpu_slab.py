@@ -444,3 +444,34 @@ def test_schur_kcycle_on_slabs(R):
     assert abs(xn(many) - xn(one)) < 1e-11 * xn(one)
     pat = r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations"
     assert re.findall(pat, many.stdout) == re.findall(pat, plain.stdout) and len(re.findall(pat, many.stdout)) == 2
+
+
+@pytest.mark.parametrize("opts,R", [([], 4), (["schur"], 2), (["schur", "nrhs=2", "f32"], 4)])
+def test_adaptive_n22_on_slabs(opts, R):
+    """BASELINE configs[4]'s driver on slabs (n22: adaptive setup passes through the batched K-cycle, optional red-black form, optional
+    fp32 K-cycle for the batched solves): one rank in slab mode = the plain driver digit for digit; R thread ranks: the same outer
+    iteration count, the same solution norm to 1e-10."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    args = [os.path.join(drivers, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "2", "1", gauge, "64"] + opts
+    env = dict(os.environ, QMG_QUIET="1")
+    plain = subprocess.run(args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run(args, cwd=drivers, env=dict(env, QMG_SLAB="1", RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run(args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    for o in (plain, one, many):
+        assert o.returncode == 0, o.stdout[-2500:] + o.stderr[-1500:]
+    it = lambda o: int(re.search(r"Multigrid converged in (\d+) iterations", o.stdout).group(1))
+    chk = lambda o: re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1)
+    xn = lambda o: float(re.search(r"\|x\|\^2 ([\d.e+-]+)", o.stdout).group(1))
+    assert it(one) == it(plain) and chk(one) == chk(plain)
+    assert it(many) == it(one) and float(chk(many)) < 1e-9
+    assert abs(xn(many) - xn(one)) < 1e-10 * xn(one)
+    if "nrhs=2" in opts:
+        pat = r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations"
+        a, b = re.findall(pat, one.stdout), re.findall(pat, many.stdout)
+        assert len(a) == 2 and len(b) == 2 and all(abs(int(u[1]) - int(v[1])) <= 1 for u, v in zip(a, b)), (a, b)
