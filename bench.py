@@ -509,6 +509,38 @@ def slab_kcycle(L, world, rank):
             "outer_iterations_per_s": float(t.group(3))}
 
 
+def slab_kcycle_c5(world, rank):
+    """BASELINE configs[4] (adaptive Wilson K-cycle, 4096^2, 4 levels, coarse nc = 8, red-black on every level) with the ONE lattice cut into
+    `world` y-slabs on every level (drivers/n22_wilson_kcycle_adaptive.cpp in slab mode).  As `also_slab_kcycle`: every rank starts its child,
+    rank 0's reports; iterations and `x_norm2` must agree across N, `setup_s` / `solve_s` are the strong-scaling curves."""
+    import re
+    import subprocess
+    drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
+    exe = os.path.join(drivers, "n22_wilson_kcycle_adaptive")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    fixture = os.path.join(ROOT, "tests", "golden", "l64t64b60_heatbath.dat")
+    env = dict(os.environ, QMG_QUIET="1", QMG_SLAB="1")
+    if "MASTER_PORT" in os.environ:
+        env["QMG_COMM_PORT"] = str(int(os.environ["MASTER_PORT"]) + 3)
+    try:
+        p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur"], cwd=drivers, env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"error": "n22_wilson_kcycle_adaptive (slab mode) timed out after 300 s on rank %d" % rank}
+    if rank != 0:
+        return None
+    m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
+    c = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
+    sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", p.stdout)
+    t = re.search(r"\[QMG-TIMING\]: setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
+    if not (m and c and sl and t) or p.returncode != 0:
+        return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
+    return {"workload": "adaptive Wilson K-cycle (n22 parameters, 1 adaptive pass), 4096x4096, 4 levels, coarse nc=8, red-black on every level, fp64, ONE lattice cut into %d y-slab(s)" % world,
+            "scaling": "strong", "world": int(sl.group(1)), "converged": m.group(1) == "converged", "outer_iterations": int(m.group(2)),
+            "true_residual_original_system": float(c.group(1)), "x_norm2": float(sl.group(3)), "setup_s": float(t.group(1)), "solve_s": float(t.group(2)),
+            "outer_iterations_per_s": float(t.group(3))}
+
+
 def pmc_traffic(L):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes, ONLY if they were taken on the
     kernel source that is being run now (sha256 of csrc/qmg_stencil.hip stamped by tools/summarize_profiles.py)."""
@@ -775,10 +807,14 @@ def main():
         slab = slab_solve(L, world, rank)
         barrier()
         slab_k = slab_kcycle(2048, world, rank) if not args.no_kcycle else None
+        barrier()
+        slab_c5 = slab_kcycle_c5(world, rank) if not args.no_kcycle else None
         if rank == 0:
             out["also_slab_solve"] = slab
             if slab_k is not None:
                 out["also_slab_kcycle"] = slab_k
+            if slab_c5 is not None:
+                out["also_slab_kcycle_c5"] = slab_c5
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fixture)
