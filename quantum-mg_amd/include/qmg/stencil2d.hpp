@@ -132,15 +132,43 @@ struct Stencil2D {
     if (!slab_halos()) { std::cout << "[QMG-ERROR]: no memory for the halo rows\n"; return; }
     const size_t hs = (size_t)d.Lx * d.nc;
     void* st = qmg::current_stream();
-    if (!qmg::ok(qmg_halo_exchange_parity(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, d.hopping || original_arrays ? halo_parities(pieces) : 0u, st),
-                 "qmg_halo_exchange")) return;
-    if (original_arrays && direct.on) {   // Wilson straight from the (global, replicated) links
-      const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs, slab_halo_lo,
-                                             slab_halo_hi, pieces, 1, 0, hs, 1u, 0, st);
-      if (rc == QMG_SUCCESS) return;
-      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+    const unsigned par = (d.hopping || original_arrays) ? halo_parities(pieces) : 0u;
+    // rows: 0 = all rows after the exchange; with more than one rank the nc = 2 kernels run the interior rows WHILE the halo rows travel
+    // (exchange on a second stream behind an event), then the two boundary rows -- what SlabWilson2D does (slab.hpp)
+    auto apply_rows = [&](int rows) -> bool {
+      if (original_arrays && direct.on) {   // Wilson straight from the (global, replicated) links
+        const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs, slab_halo_lo,
+                                               slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st);
+        if (rc == QMG_SUCCESS) return true;
+        if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) return qmg::ok(rc, "qmg_wilson_apply_direct");
+      }
+      return qmg::ok(qmg_stencil_apply_slab(QMG_C64, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st), "qmg_stencil_apply_slab");
+    };
+    const bool overlap = par && qmg::slab().world > 1 && d.nc == 2 && d.Ly >= 4 && lhs != rhs && slab_overlap_ready();
+    if (!overlap) {
+      if (!qmg::ok(qmg_halo_exchange_parity(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, par, st), "qmg_halo_exchange")) return;
+      apply_rows(0);
+      return;
     }
-    qmg::ok(qmg_stencil_apply_slab(QMG_C64, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, 1, 0, hs, 1u, 0, st), "qmg_stencil_apply_slab");
+    qmg::ok(qmg_event_record(slab_ev_rhs, st), "qmg_event_record");
+    qmg::ok(qmg_stream_wait_event(slab_comm_stream, slab_ev_rhs), "qmg_stream_wait_event");
+    if (!qmg::ok(qmg_halo_exchange_parity(QMG_C64, rhs, d.Lx, d.Ly, d.nc, slab_halo_lo, slab_halo_hi, 1, 0, hs, par, slab_comm_stream), "qmg_halo_exchange")) return;
+    qmg::ok(qmg_event_record(slab_ev_halo, slab_comm_stream), "qmg_event_record");
+    if (!apply_rows(1)) return;
+    qmg::ok(qmg_stream_wait_event(st, slab_ev_halo), "qmg_stream_wait_event");
+    apply_rows(2);
+  }
+  void *slab_comm_stream, *slab_ev_rhs, *slab_ev_halo;
+  bool slab_overlap_ready() {
+    static const bool wanted = !(getenv("QMG_SLAB_OVERLAP") && atoi(getenv("QMG_SLAB_OVERLAP")) == 0);
+    if (!wanted) return false;
+    if (!slab_comm_stream) {
+      if (qmg_stream_create(&slab_comm_stream) != QMG_SUCCESS || qmg_event_create(&slab_ev_rhs) != QMG_SUCCESS || qmg_event_create(&slab_ev_halo) != QMG_SUCCESS) {
+        slab_comm_stream = 0;
+        return false;
+      }
+    }
+    return true;
   }
   bool direct_usable(const complex<double>* cl, const complex<double>* ho) const {
     return direct.on && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
@@ -194,6 +222,7 @@ struct Stencil2D {
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
     direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false;
     slab_halo_lo = slab_halo_hi = 0;
+    slab_comm_stream = slab_ev_rhs = slab_ev_halo = 0;
     f32.clover16 = f32.hopping16 = f32.rbj_hopping16 = 0; f32.half_on = false;
     built_dagger = false; dagger_clover = dagger_hopping = dagger_twolink = dagger_corner = 0;
     built_rbjacobi = false; rbjacobi_clover = rbjacobi_hopping = rbjacobi_twolink = rbjacobi_corner = rbjacobi_cinv = 0;
@@ -213,6 +242,7 @@ struct Stencil2D {
     drop_direct_links();
     if (slab_halo_lo) deallocate_vector(&slab_halo_lo);
     if (slab_halo_hi) deallocate_vector(&slab_halo_hi);
+    if (slab_comm_stream) { qmg_stream_sync(slab_comm_stream); qmg_event_destroy(slab_ev_rhs); qmg_event_destroy(slab_ev_halo); qmg_stream_destroy(slab_comm_stream); }
     built_dagger = built_rbjacobi = built_rbj_dagger = generated = false;
   }
 
