@@ -899,20 +899,25 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       }
     };
     auto load_vectors = [&](int pc, int set) {    // the k right-hand sides at the piece's neighbour site
+      // a y-slab's rows -1 / Ly: the piece's neighbour row comes from the halo buffer ([system][parity][hr][NC]; a row-uniform choice)
+      const bool h_hi = pc == 2 && a.halo_hi && y + 1 == a.Ly, h_lo = pc == 4 && a.halo_lo && y == 0;
+      const void* vbase = h_hi ? a.halo_hi : h_lo ? a.halo_lo : a.rhs;
+      const long vsite = (h_hi || h_lo) ? (long)(1 - p) * a.hr + j : nb_of(pc);
+      auto voff = [&](int k) -> long { return (h_hi || h_lo) ? (long)(a.use_idx ? (int)a.ridx[k] : k) * a.halo_stride : rhs_offset(a, k); };
       if constexpr (VL) {                         // lane-linear over [k][c]: element e = g*64 + lane -> (k = e / NC, c = e % NC)
-        const long so = nb_of(pc) * NC;
+        const long so = vsite * NC;
 #pragma unroll
         for (int g = 0; g < NXG; g++) {
           const int e = g * WAVE + lane;
           const int k = e / NC, c = e - k * NC;
-          XG[g] = (k < nk) ? ldv<V32>(a.rhs, rhs_offset(a, k) + so + c) : cmake(0.0, 0.0);
+          XG[g] = (k < nk) ? ldv<V32>(vbase, voff(k) + so + c) : cmake(0.0, 0.0);
         }
       } else {
-        const long xo = koff + nb_of(pc) * NC;    // B-operand layout straight from global memory
+        const long xo = voff(kcol & 15) + vsite * NC;    // B-operand layout straight from global memory
 #pragma unroll
         for (int q = 0; q < KS; q++) {
           const int c = 4 * q + lq;
-          const cplx xv = (kval && c < NC) ? ldv<V32>(a.rhs, xo + c) : cmake(0.0, 0.0);
+          const cplx xv = (kval && c < NC) ? ldv<V32>(vbase, xo + c) : cmake(0.0, 0.0);
           if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
           else B[set][q] = xv;
         }
@@ -1303,7 +1308,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   // kernel B's shared tile wins (nc = 8, 1024^2, 3 rhs: 1.06 vs 1.39 ms) and it serves every other nc
   // (nc <= 16: kernel B with one 4-accumulator pass still wins at exactly 4 systems -- nc = 8, 1024^2: 1.21 vs 1.52 ms;
   //  nc = 16, 512^2: 0.98 vs 1.08 ms -- so there the matrix cores take over from 5)
-  if (a.nrhs >= (nc <= 16 ? 5 : 4) && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32) && !slab) {   // (kernel C has no halo step: a slab's batches go through kernel B)
+  if (a.nrhs >= (nc <= 16 ? 5 : 4) && g_stencil_mfma && (nc == 8 || nc == 12 || nc == 16 || nc == 24 || nc == 32)) {
     // kernel C: up to 16 right-hand sides per pass share one read of the matrices
     const unsigned gx = (unsigned)((a.hr + BLOCK / WAVE - 1) / (BLOCK / WAVE));
     dim3 grid(gx, gy), block(BLOCK);

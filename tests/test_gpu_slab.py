@@ -475,3 +475,36 @@ def test_adaptive_n22_on_slabs(opts, R):
         pat = r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations"
         a, b = re.findall(pat, one.stdout), re.findall(pat, many.stdout)
         assert len(a) == 2 and len(b) == 2 and all(abs(int(u[1]) - int(v[1])) <= 1 for u, v in zip(a, b)), (a, b)
+
+
+@pytest.mark.parametrize("nc,nrhs,mask,f32", [(8, 6, 0b111111, False), (12, 8, 0xFF, False), (24, 5, 0b11011, False), (24, 16, 0xFFFF, False), (8, 8, 0xFF, True), (24, 7, 0x7F, True)])
+def test_coarse_batches_on_slabs_through_the_mfma_kernel(nc, nrhs, mask, f32):
+    """Kernel C (the multi-rhs coarse apply on the matrix cores) with the halo step: a slab's batch of right-hand sides takes rows -1 / Ly
+    from the halo buffers; bit for bit the rows of the single-domain kernel C, in fp64 (f64 MFMA) and with complex<float> matrices and
+    vectors (f32 MFMA)."""
+    Lx, Ly, R = 16, 16, 2
+    vol = Lx * Ly
+    n = vol * nc
+    vt = np.complex64 if f32 else np.complex128
+    dt = qmg.C32 if f32 else qmg.C64
+    clover, hopping = cs.gaussian_cvec(vol * nc * nc, 1).astype(vt), cs.gaussian_cvec(4 * vol * nc * nc, 2).astype(vt)
+    x, l0 = cs.gaussian_cvec(n * nrhs, 3).astype(vt), cs.gaussian_cvec(n * nrhs, 4).astype(vt)
+    shifts = (0.1 + 0.05j, 0.02, 0.03)
+    d = qmg.make_desc(Lx, Ly, nc, D(clover), D(hopping), *shifts)
+    pieces = qmg.P_ALL | qmg.P_ZERO
+    want = D(l0)
+    qmg.stencil_apply_t(dt, d, want, D(x), pieces, nrhs, n, mask)
+    want = want.to_host()
+    Ll, row = Ly // R, (Lx // 2) * nc
+    nl = Lx * Ll * nc
+    xs = x.reshape(nrhs, 2, Ly, row)
+    for r in range(R):
+        y0 = r * Ll
+        dl = qmg.make_desc(Lx, Ll, nc, D(rows(clover, Ly, (Lx // 2) * nc * nc, y0, Ll)), D(rows(hopping, Ly, (Lx // 2) * nc * nc, y0, Ll)), *shifts)
+        dx = D(np.concatenate([rows(x[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+        out = D(np.concatenate([rows(l0[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+        lo, hi = D(np.ascontiguousarray(xs[:, :, (y0 - 1) % Ly]).reshape(-1)), D(np.ascontiguousarray(xs[:, :, (y0 + Ll) % Ly]).reshape(-1))
+        qmg.stencil_apply_slab(dt, dl, out, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=0)
+        got = out.to_host()
+        for k in range(nrhs):
+            assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], Ly, row, y0, Ll)), (nc, r, k)
