@@ -462,6 +462,12 @@ struct Stencil2D {
         if (rc == QMG_SUCCESS) return;
         if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
       }
+      if (f && f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices (nc = 2), fp32 vectors
+        d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
+        d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
+        qmg::ok(qmg_stencil_apply_slab(QMG_C32 | QMG_SLAB_H16, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
+        return;
+      }
       if (f) {
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
