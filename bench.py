@@ -261,7 +261,7 @@ def kcycle_cpu_reference():
     try:
         with tempfile.TemporaryDirectory() as tmp:
             p = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle"), str(L), str(MASS), "6.0", str(n_refine), str(dof), fixture, "64"], cwd=drivers,
-                               env=dict(os.environ, QMG_QUIET="1", QMG_DUMP_DIR=tmp), capture_output=True, text=True, timeout=300)
+                               env=dict(os.environ, QMG_QUIET="1", QMG_DUMP_DIR=tmp), capture_output=True, text=True, timeout=180)
             m = re.search(r"setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
             git = int(re.search(r"Multigrid converged in (\d+) iterations", p.stdout).group(1))
             nullvecs = [np.fromfile(os.path.join(tmp, "nullvecs_level%d.bin" % l), dtype=np.complex128) for l in range(n_refine)]
@@ -458,14 +458,14 @@ def slab_solve(L, world, rank):
         subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
     try:
         p = subprocess.run([exe, str(L), "0.05", "6.0", "200", "1337", "1e-10", "1", "1"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
-                           capture_output=True, text=True, timeout=240)
+                           capture_output=True, text=True, timeout=180)
     except subprocess.TimeoutExpired:
-        return {"error": "slab_wilson_solve timed out after 240 s on rank %d" % rank}
+        return {"error": "slab_wilson_solve timed out after 180 s on rank %d" % rank}
     m = re.search(r"BiCGStab-6 (converged|FAILED) in (\d+) iterations, ([\d.e+-]+) s, (\d+) applies, true relative residual ([\d.e+-]+), \|b\| [\d.e+-]+, \|x\|\^2 ([\d.e+-]+), world (\d+)", p.stdout)
     a = re.search(r"apply_M on a slab: ([\d.e+-]+) ms with the exchange overlapped, ([\d.e+-]+) ms serialised", p.stdout)
     v = re.findall(r"slab apply vs single-domain apply, rel diff ([\d.e+-]+) \((ok|MISMATCH)\)", p.stdout)
     if rank != 0:
-        return None
+        return {"rank": rank, "rc": p.returncode} if p.returncode == 0 else {"error": "rc %d on rank %d" % (p.returncode, rank)}
     if not m or p.returncode != 0:
         return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
     return {"workload": "one Wilson solve (BiCGStab-6, tol 1e-10, mass 0.05, beta 6.0 device heatbath) on ONE %dx%d lattice cut into %d y-slab(s)" % (L, L, world),
@@ -492,11 +492,11 @@ def slab_kcycle(L, world, rank):
         env = dict(os.environ, QMG_QUIET="1")
         if "MASTER_PORT" in os.environ:   # its own rendezvous port (the slab_solve children used MASTER_PORT + 1 a moment ago)
             env["QMG_COMM_PORT"] = str(int(os.environ["MASTER_PORT"]) + 2)
-        p = subprocess.run([exe, str(L), str(MASS), "6.0", "2", "8", fixture, "64"], cwd=drivers, env=env, capture_output=True, text=True, timeout=300)
+        p = subprocess.run([exe, str(L), str(MASS), "6.0", "2", "8", fixture, "64"], cwd=drivers, env=env, capture_output=True, text=True, timeout=180)
     except subprocess.TimeoutExpired:
-        return {"error": "n13_wilson_kcycle_slab timed out after 300 s on rank %d" % rank}
+        return {"error": "n13_wilson_kcycle_slab timed out after 180 s on rank %d" % rank}
     if rank != 0:
-        return None
+        return {"rank": rank, "rc": p.returncode} if p.returncode == 0 else {"error": "rc %d on rank %d" % (p.returncode, rank)}
     m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
     c = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
     sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", p.stdout)
@@ -524,11 +524,11 @@ def slab_kcycle_c5(world, rank):
     if "MASTER_PORT" in os.environ:
         env["QMG_COMM_PORT"] = str(int(os.environ["MASTER_PORT"]) + 3)
     try:
-        p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur"], cwd=drivers, env=env, capture_output=True, text=True, timeout=300)
+        p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur"], cwd=drivers, env=env, capture_output=True, text=True, timeout=180)
     except subprocess.TimeoutExpired:
-        return {"error": "n22_wilson_kcycle_adaptive (slab mode) timed out after 300 s on rank %d" % rank}
+        return {"error": "n22_wilson_kcycle_adaptive (slab mode) timed out after 180 s on rank %d" % rank}
     if rank != 0:
-        return None
+        return {"rank": rank, "rc": p.returncode} if p.returncode == 0 else {"error": "rc %d on rank %d" % (p.returncode, rank)}
     m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
     c = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
     sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", p.stdout)
@@ -803,18 +803,33 @@ def main():
         out["also_kcycle_c5_shape"] = kcycle_c5_shape()
 
     if not args.no_also:   # every rank takes part: the slabs of one lattice
+        def everyone_ok(res):   # a leg that failed on ANY rank ends the slab legs for all ranks (the next leg's children would only wait for each other)
+            good = 1.0 if (res is not None and "error" not in res) else 0.0
+            if dist is not None:
+                t = torch.tensor([good], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                good = t.item()
+            return good > 0.5
         barrier()
         slab = slab_solve(L, world, rank)
-        barrier()
-        slab_k = slab_kcycle(2048, world, rank) if not args.no_kcycle else None
-        barrier()
-        slab_c5 = slab_kcycle_c5(world, rank) if not args.no_kcycle else None
+        go_on = everyone_ok(slab)
+        slab_k = slab_c5 = None
+        if go_on and not args.no_kcycle:
+            barrier()
+            slab_k = slab_kcycle(2048, world, rank)
+            go_on = everyone_ok(slab_k)
+        if go_on and not args.no_kcycle:
+            barrier()
+            slab_c5 = slab_kcycle_c5(world, rank)
+            go_on = everyone_ok(slab_c5)
         if rank == 0:
             out["also_slab_solve"] = slab
             if slab_k is not None:
                 out["also_slab_kcycle"] = slab_k
             if slab_c5 is not None:
                 out["also_slab_kcycle_c5"] = slab_c5
+            if not go_on:
+                out["also_slab_note"] = "a slab leg failed on some rank; the remaining slab legs were skipped"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fixture)
