@@ -217,7 +217,7 @@ def test_slab_solve_driver_on_one_rank(forced_rccl):
     assert bad.returncode == 0 or "do not split" in bad.stdout      # 6 rows on one rank are fine; the refusal needs world > 1 (not reachable on one GPU)
 
 
-@pytest.mark.parametrize("L,R", [(64, 2), (64, 4), (128, 8)])
+@pytest.mark.parametrize("L,R", [(64, 2), (64, 4), (128, 8), (96, 3), (96, 6)])
 def test_slab_solve_with_ranks_emulated_by_threads(L, R):
     """More than one rank on a one-GPU box: R host threads attach as ranks (qmg_comm_emulate_*, csrc/qmg_comm.hip), the transport
     becomes device copies + host sums behind thread barriers, and everything above it is the code the RCCL path runs -- peer
