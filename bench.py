@@ -139,10 +139,9 @@ class StaggeredMultiRHS:
         from importlib import import_module
         sharding = import_module("quantum-mg_amd.sharding")
         q = self.qmg
-        q.stencil_apply(self.desc, self.lhs, self.rhs, q.P_ALL | q.P_ZERO, nrhs=self.nrhs, vec_stride=self.vol)
+        # the apply leaves |lhs_k|^2 from the same pass (kernel A2 with NORM): the vectors are not read again for the norms
         base = self.norms.data_ptr() + 8 * self.rank * self.nrhs
-        for k in range(self.nrhs):
-            q.check(q.lib().qmg_norm2sq(C.c_void_p(self.lhs.offset(k * self.vol)), C.c_size_t(self.vol), C.c_void_p(base + 8 * k), None, None))
+        q.stencil_apply_norm2(self.desc, self.lhs, self.rhs, q.P_ALL | q.P_ZERO, nrhs=self.nrhs, vec_stride=self.vol, norms_dev=base)
         # the buffer is reused from step to step: the slots of the other ranks are cleared before the sum (sharding.py)
         sharding.allgather_by_allreduce(self.norms, self.world * self.nrhs, self.rank, self.world, self.dist, own=(self.rank * self.nrhs, (self.rank + 1) * self.nrhs))
 
@@ -430,16 +429,16 @@ def wilson_from_links(qmg, L, fixture, steps, warmup, barrier):
 
 def staggered_8rhs(qmg, L, fixture, steps, warmup, barrier, torch):
     """BASELINE configs[3] per-GPU workload on this one GPU: staggered 4096^2, 8 right-hand sides sharing one matrix read,
-    per-RHS norm2sq, and the (here one-rank) all-reduce slot buffer."""
+    per-RHS |lhs|^2 from the same pass (qmg_stencil_apply_norm2), and the (here one-rank) all-reduce slot buffer."""
     wl = StaggeredMultiRHS(qmg, L, fixture, 1337, 8, 0, 1, None, torch)
     gate = wl.parity_gate(fixture)
     wall, kern_ms = timed(qmg, wl, steps, warmup, barrier)
     sites_rhs = L * L * 8
-    b = (wl.bytes_per_site_rhs + 16.0) * sites_rhs
+    b = wl.bytes_per_site_rhs * sites_rhs
     out = {"workload": "staggered apply + per-RHS norm2sq, %dx%d, nc=1, 8 rhs sharing one read of the hopping matrices (BASELINE configs[3] per-GPU share)" % (L, L),
            "gflops": sites_rhs * wl.FLOP_PER_SITE_RHS * steps / wall / 1e9, "ms_per_step": wall / steps * 1e3, "achieved_gb_per_s": b / (kern_ms * 1e-3) / 1e9,
            "frac_of_hbm_peak": b / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "parity_gate_rel_l2": gate,
-           "note": "whole step: apply (64/nrhs + 32 B/site/rhs) + norm2sq (16 B/site/rhs); the N-GPU form is `--workload staggered`"}
+           "note": "whole step in one pass: apply with fused per-RHS norms (64/nrhs + 32 B/site/rhs; a separate norm2sq would re-read 16); the N-GPU form is `--workload staggered`"}
     wl.free()
     return out
 
@@ -739,9 +738,10 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
                "config": {"workload": "staggered apply + per-RHS norm2sq + one all-reduce, %dx%d U(1) tiled, nc=1, %d rhs per GPU (%d total)" % (L, L, args.nrhs, world * args.nrhs),
                           "lattice": [L, L], "nc": 1, "mass": wl.MASS, "rhs_per_gpu": args.nrhs, "parallelism": "rhs sharded over ranks, 1 all-reduce of %d doubles per step" % (world * args.nrhs)},
-               "roofline": {"bound": "hbm", "achieved": (wl.bytes_per_site_rhs + 16.0) * sites_rhs / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": (wl.bytes_per_site_rhs + 16.0) * sites_rhs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "k_stencil_pair<1,2> (nrhs loop) + k_reduce", "note": "whole step: apply (64/nrhs + 32 B/site/rhs) + norm2sq (16 B/site/rhs)"},
+               "roofline": {"bound": "hbm", "achieved": wl.bytes_per_site_rhs * sites_rhs / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": wl.bytes_per_site_rhs * sites_rhs / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "k_stencil_pair<double,1,2,NORM,PF> (nrhs loop, fused norms) + k_apply_norm_final",
+                            "note": "whole step in one pass: apply with fused per-RHS norms, 64/nrhs + 32 B/site/rhs (a separate norm2sq would re-read 16)"},
                "parity_gate_rel_l2": gate_err}
         if rank == 0:
             print(json.dumps(out), flush=True)

@@ -121,6 +121,14 @@ int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, in
  * other (the reference's in-place use, stencil_2d.h:1904, staggered.h:236). */
 int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                       int nrhs, size_t vec_stride, void* stream);
+/* The apply with the norms of its results from the same pass: lhs_k (+)= pieces(M) rhs_k and norms[k] = |lhs_k|^2 (the
+ * apply followed by norm2sq of vector_reductions.h:97-120 without re-reading the vector: 40 instead of 56 B/site/rhs for
+ * the staggered operator).  fp64, nc = 1 or 2, pieces touching BOTH parities, lhs != rhs, nrhs <= 16; anything else, or a
+ * call while distributed reductions are on, is QMG_ERR_UNSUPPORTED.  lhs receives the bytes qmg_stencil_apply writes; the
+ * norms are summed in a fixed order (run-to-run reproducible), not in qmg_norm2sq's order (they agree to rounding).
+ * norms_dev: nrhs doubles in device memory or NULL; norms_host: nrhs doubles or NULL (then the stream is synchronised). */
+int qmg_stencil_apply_norm2(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
+                            double* norms_dev, double* norms_host, void* stream);
 /* Same, for a lock-step batch of at most 16 systems of which only those with their bit set in `mask` are read or
  * written.  With nc in {8,12,16,24,32} and two or more active systems the apply runs as an (nc x nc).(nc x k)
  * contraction on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the matrices read once for all k. */

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
-    "qmg_convert_to_c16", "qmg_stencil_apply_h16",
+    "qmg_convert_to_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_norm2",
     "qmg_wilson_apply_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
@@ -186,6 +186,16 @@ def make_desc(Lx, Ly, nc, clover, hopping, shift=0.0, eo_shift=0.0, dof_shift=0.
 def stencil_apply(desc, lhs, rhs, pieces=P_ALL | P_ZERO, nrhs=1, vec_stride=0, stream=None):
     check(lib().qmg_stencil_apply(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), C.c_int(nrhs),
                                   C.c_size_t(vec_stride), C.c_void_p(stream)), "qmg_stencil_apply")
+
+
+def stencil_apply_norm2(desc, lhs, rhs, pieces=P_ALL | P_ZERO, nrhs=1, vec_stride=0, norms_dev=None, stream=None):
+    """The apply and |lhs_k|^2 of its results in one pass.  With norms_dev (a device pointer to nrhs doubles) nothing
+    synchronises and None is returned; otherwise the norms come back as a numpy array."""
+    out = None if norms_dev is not None else np.full(nrhs, np.nan)
+    check(lib().qmg_stencil_apply_norm2(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), C.c_int(nrhs), C.c_size_t(vec_stride),
+                                        C.c_void_p(norms_dev), None if out is None else out.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.c_void_p(stream)), "qmg_stencil_apply_norm2")
+    return out
 
 
 def cshift(lhs, rhs, cdir, eo, dof, Lx, Ly, stream=None):

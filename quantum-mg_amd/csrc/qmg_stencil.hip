@@ -55,6 +55,8 @@ struct StencilArgs {
   const void* halo_lo;
   const void* halo_hi;
   long halo_stride;
+  // fused |lhs_k|^2 (kernel A2 with NORM, qmg_stencil_apply_norm2): one partial per (row group, block, wavefront, system)
+  double* norm_part;
 #ifdef QMG_DIAGNOSTICS
   int ablate;        // tools-only build (make DIAG=1; tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 #endif
@@ -294,7 +296,16 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_elem(const StencilArgs a) {
 // wave), which takes the launch out of the "a million 6-KiB waves" regime where wave dispatch,
 // not HBM, sets the pace (tools/membw2.hip: 5.3 TB/s at 1M blocks vs 6.4-6.7 TB/s at 64K).
 // ------------------------------------------------------------------------------------------
-template <typename T, int NC, int ROWS, bool NT, bool NTS>
+// NORM: the kernel also leaves |lhs_k|^2 of what it stored, as one partial per (block, system) in a.norm_part (summed in a
+// fixed order by k_apply_norm_final) -- the residual norm of a Krylov step without re-reading the vector it has just written
+// (16 of a staggered step's 56 B/site/rhs).  Inside the loop over the systems a lane only adds to its own LDS slot
+// ([system][thread], dynamic shared memory): a wavefront reduction per system there (four ds_bpermute round trips in the
+// dependent chain of every iteration) cost 0.15 ms on a 1.00 ms apply; the cross-lane sums happen once, after the loop.
+// Lane groups past the end of the half row stay (on the last column, storing nothing) so that the block-wide steps see
+// every thread.
+// PF (batches): the right-hand side of system k+1 is requested before system k is multiplied, so a wavefront's loads stay in
+// flight through its arithmetic and stores (the kernel sits at 2 waves/SIMD either way: 176 -> 2xx VGPRs).
+template <typename T, int NC, int ROWS, bool NT, bool NTS, bool NORM = false, bool PF = false>
 __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
   typedef KA<T, NC> K;
   typedef typename K::ct ct;
@@ -303,8 +314,15 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
   const int e = threadIdx.x % E;
   const int r = e / K::LPR, c0 = (e % K::LPR) * CW;
   const int vf = e % K::LPR;
-  const int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
-  if (j >= a.hr) return;
+  int j = blockIdx.x * (BLOCK / E) + threadIdx.x / E;
+  bool live = true;
+  if (j >= a.hr) {
+    if (!NORM) return;
+    live = false; j = a.hr - 1;
+  }
+  extern __shared__ double norm_sm[];
+  if (NORM)
+    for (int k = 0; k < a.nrhs; k++) norm_sm[k * BLOCK + threadIdx.x] = 0.0;
   const int ngroups = a.Ly / ROWS;
 
   bool do_clover[2], do_shift[2], do_zero[2];
@@ -338,14 +356,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
           m[rr][p][d] = ((hop_mask[p] >> d) & 1u) ? ld_frag<T, NC, NT>(a.hopping, ((long)d * a.size_cm) / CW + site * FPS + e) : zero_frag<T, NC>();
       }
 
-    for (int k = 0; k < a.nrhs; k++) {
-      const ct* x = reinterpret_cast<const ct*>(a.rhs) + rhs_offset(a, k);
-      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset(a, k);
-      const ct* xe = x;                       // even half
-      const ct* xo = x + a.half_vol * NC;     // odd half
-
-      // ---- right-hand side: rows y0-1 .. y0+ROWS at column j, both parities
-      Frag Ec[ROWS + 2], Oc[ROWS + 2];
+    // one system's right-hand side: rows y0-1 .. y0+ROWS at column j, both parities, and the one x-neighbour per row that
+    // is not the partner site
+    struct XF { Frag Ec[ROWS + 2], Oc[ROWS + 2], Es[ROWS], Os[ROWS]; };
+    auto load_x = [&](XF& v, int k) {
+      const ct* xe = reinterpret_cast<const ct*>(a.rhs) + rhs_offset(a, k);   // even half
+      const ct* xo = xe + a.half_vol * NC;                                    // odd half
 #pragma unroll
       for (int t = 0; t < ROWS + 2; t++) {
         int yy = y0 - 1 + t;
@@ -353,25 +369,38 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
         if (yy >= a.Ly) yy -= a.Ly;
         const bool edge = (t == 0 || t == ROWS + 1);
         if (!edge || any_hop) {
-          Ec[t] = ld_frag<T, NC, false>(xe, ((long)yy * a.hr + j) * VPS + vf);
-          Oc[t] = ld_frag<T, NC, false>(xo, ((long)yy * a.hr + j) * VPS + vf);
+          v.Ec[t] = ld_frag<T, NC, false>(xe, ((long)yy * a.hr + j) * VPS + vf);
+          v.Oc[t] = ld_frag<T, NC, false>(xo, ((long)yy * a.hr + j) * VPS + vf);
         } else {
-          Ec[t] = Oc[t] = zero_frag<T, NC>();
+          v.Ec[t] = v.Oc[t] = zero_frag<T, NC>();
         }
       }
-      // ---- and the one x-neighbour per row that is not the partner site
-      Frag Es[ROWS], Os[ROWS];
 #pragma unroll
       for (int rr = 0; rr < ROWS; rr++) {
         const int y = y0 + rr;
         const int se = y & 1;                    // even site: x = 2j + se ; odd site: x = 2j + 1 - se
         if (any_hop) {
-          Os[rr] = ld_frag<T, NC, false>(xo, ((long)y * a.hr + (se ? jr : jl)) * VPS + vf);
-          Es[rr] = ld_frag<T, NC, false>(xe, ((long)y * a.hr + (se ? jl : jr)) * VPS + vf);
+          v.Os[rr] = ld_frag<T, NC, false>(xo, ((long)y * a.hr + (se ? jr : jl)) * VPS + vf);
+          v.Es[rr] = ld_frag<T, NC, false>(xe, ((long)y * a.hr + (se ? jl : jr)) * VPS + vf);
         } else {
-          Os[rr] = Es[rr] = zero_frag<T, NC>();
+          v.Os[rr] = v.Es[rr] = zero_frag<T, NC>();
         }
       }
+    };
+
+    XF cur;
+    if (PF) load_x(cur, 0);
+    for (int k = 0; k < a.nrhs; k++) {
+      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset(a, k);
+      double nrm = 0.0;
+      XF nxt;
+      if (!PF) load_x(cur, k);
+      else {
+        if (k + 1 < a.nrhs) load_x(nxt, k + 1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from sinking the prefetch below the arithmetic
+      }
+      const Frag (&Ec)[ROWS + 2] = cur.Ec, (&Oc)[ROWS + 2] = cur.Oc;
+      const Frag (&Es)[ROWS] = cur.Es, (&Os)[ROWS] = cur.Os;
 
 #pragma unroll
       for (int rr = 0; rr < ROWS; rr++) {
@@ -399,14 +428,45 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
           fmac<T, NC>(acc, sh[p], own_u);
           row_sum<T, NC>(acc);
           const bool touch = do_clover[p] || hop_mask[p] || do_shift[p] || do_zero[p];
-          if (c0 == 0 && touch) {
+          if (c0 == 0 && touch && live) {
             const long o = ((long)p * a.half_vol + (long)y * a.hr + j) * NC + r;
             if (!do_zero[p]) { const ct prev = out[o]; acc.x += prev.x; acc.y += prev.y; }
             st_elem<T, NTS>(out, o, acc);
+            if (NORM) { nrm = fma((double)acc.x, (double)acc.x, nrm); nrm = fma((double)acc.y, (double)acc.y, nrm); }
           }
         }
       }
+      if (NORM) norm_sm[k * BLOCK + threadIdx.x] += nrm;
+      if (PF && k + 1 < a.nrhs) cur = nxt;
     }
+  }
+  if (NORM) {
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int k = threadIdx.x / WAVE; k < a.nrhs; k += BLOCK / WAVE) {
+      double t = norm_sm[k * BLOCK + lane];
+#pragma unroll
+      for (int w = 1; w < BLOCK / WAVE; w++) t += norm_sm[k * BLOCK + w * WAVE + lane];
+      t = wave_sum(t);
+      if (lane == 0) a.norm_part[((long)blockIdx.y * gridDim.x + blockIdx.x) * a.nrhs + k] = t;
+    }
+  }
+}
+
+// the partials of system q (stride = systems), summed in a fixed order
+__global__ __launch_bounds__(BLOCK) void k_apply_norm_final(const double* __restrict__ part, long nparts, int stride, double* __restrict__ out) {
+  __shared__ double sm[BLOCK / WAVE];
+  const int q = blockIdx.x;
+  double t = 0.0;
+  for (long i = threadIdx.x; i < nparts; i += BLOCK) t += part[i * stride + q];
+  t = wave_sum(t);
+  if ((threadIdx.x & (WAVE - 1)) == 0) sm[threadIdx.x / WAVE] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = sm[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / WAVE; w++) r += sm[w];
+    out[q] = r;
   }
 }
 
@@ -1092,6 +1152,7 @@ static int g_stencil_ablate = 0;
 #endif
 static int g_stencil_site = 3;    // tuning knob: nc 2 through the site kernel (qmg_site.hip): bit 0 fp64 where it is faster, bit 1 fp32, bit 2 fp64 always
 static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (kernel A), 1/2 = paired parities x 1/2 rows (kernel A2)
+static int g_pair_prefetch = 1;   // tuning knob: 1 = kernel A2 prefetches the next system's right-hand side in fp64 batches
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
 static int g_mfma_vl = 1;        // tuning knob: 1 = kernel C loads / stores the right-hand sides coalesced through an LDS slice, 0 = operand-layout global accesses
@@ -1132,6 +1193,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
 #endif
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "pair_prefetch")) { g_pair_prefetch = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_site")) { g_stencil_site = value; return QMG_SUCCESS; }
   if (!strcmp(key, "site_block")) { if (value != 64 && value != 128 && value != 256) return QMG_ERR_INVALID; g_site_block = value; return QMG_SUCCESS; }
   if (!strcmp(key, "site_gy")) { g_site_gy = value; return QMG_SUCCESS; }
@@ -1149,7 +1211,8 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0, const SlabHalo* slab = nullptr);
+                              const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0, const SlabHalo* slab = nullptr,
+                              double* norms_dev = nullptr);
 
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
@@ -1186,6 +1249,35 @@ extern "C" int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, con
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1);
 }
 
+// lhs_k (+)= pieces(M) rhs_k and norms[k] = |lhs_k|^2 from the same pass (the vector is not read again): fp64, nc = 1 or 2,
+// both parities written, lhs != rhs, nrhs <= 16 (QMG_ERR_UNSUPPORTED otherwise; also under distributed reductions, where the
+// caller sums the norms itself).  norms_dev: nrhs doubles in device memory, or NULL; norms_host: nrhs doubles, or NULL
+// (synchronises the stream).  The bytes of lhs are those qmg_stencil_apply writes.
+extern "C" int qmg_stencil_apply_norm2(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
+                                       double* norms_dev, double* norms_host, void* stream) {
+  if (!norms_dev && !norms_host) return QMG_ERR_INVALID;
+  if (nrhs < 1 || nrhs > 16) return QMG_ERR_INVALID;
+  if (dist_reductions_on()) return QMG_ERR_UNSUPPORTED;
+  if (!(pieces & (QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E)) || !(pieces & (QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O)))
+    return QMG_ERR_UNSUPPORTED;   // a parity left untouched: its part of |lhs|^2 is not seen by the kernel
+  static thread_local double* own = nullptr;
+  static thread_local int own_dev = -1;
+  double* res = norms_dev;
+  if (!res) {
+    int dev = 0;
+    QMG_HIP_CHECK(hipGetDevice(&dev));
+    if (own_dev != dev) { QMG_HIP_CHECK(hipMalloc((void**)&own, sizeof(double) * 16)); own_dev = dev; }
+    res = own;
+  }
+  const int rc = stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 0, 0, nullptr, res);
+  if (rc) return rc;
+  if (norms_host) {
+    QMG_HIP_CHECK(hipMemcpyAsync(norms_host, res, sizeof(double) * nrhs, hipMemcpyDeviceToHost, as_stream(stream)));
+    QMG_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  }
+  return QMG_SUCCESS;
+}
+
 // Either storage precision, masked batch semantics.  QMG_C64: qmg_stencil_apply_batch.  QMG_C32: matrices AND vectors are
 // complex<float>; nc in {1,2,4} run kernel A in fp32 arithmetic, every other nc the fp32-tile kernels B32 / B / C with
 // fp32 vector loads and stores around their fp64 accumulation.
@@ -1203,8 +1295,12 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1, 1);
 }
 
+// partials of the fused norms (one buffer per host thread = per rank, grown on demand)
+struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; };
+static thread_local NormWorkspace g_norm_ws;
+
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab) {
+                              const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab, double* norms_dev) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -1219,7 +1315,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
   if (slab && mat32 != vec32) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2) or kernel B (any nc), matrices and vectors in ONE precision
-  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
+  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && !norms_dev && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
     const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !slab && !(g_stencil_site & 4), slab);
     if (rc != SITE_DECLINED) return rc;
   }
@@ -1235,6 +1331,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.halo_lo = slab ? slab->lo : nullptr;
   a.halo_hi = slab ? slab->hi : nullptr;
   a.halo_stride = slab ? slab->stride : 0;
+  a.norm_part = nullptr;
   for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
 #ifdef QMG_DIAGNOSTICS
   a.ablate = g_stencil_ablate;
@@ -1252,6 +1349,39 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   unsigned gy = a.nrows > 65535 ? 65535u : (unsigned)a.nrows;
   if (g_stencil_rows > 0 && gy > (unsigned)g_stencil_rows) gy = (unsigned)g_stencil_rows;
   hipStream_t st = as_stream(stream);
+
+  if (norms_dev) {
+    // apply + |lhs_k|^2 in one pass: kernel A2 in fp64, nc = 1 or 2, every site written
+    if (vec32 || mat32 || slab || ridx || !(nc == 1 || nc == 2) || a.par_count != 2 || lhs == rhs || nrhs > 16) return QMG_ERR_UNSUPPORTED;
+    const int rows = (d->Ly % 2 == 0) ? 2 : 1;
+    const unsigned gx = (unsigned)((a.hr + BLOCK / (nc * nc) - 1) / (BLOCK / (nc * nc)));
+    const long ngroups = d->Ly / rows;
+    const unsigned gyp = ngroups > 65535 ? 65535u : (unsigned)ngroups;
+    const long nparts = (long)gyp * gx;            // one partial per block and system
+    const size_t smem = sizeof(double) * BLOCK * (size_t)nrhs;
+    int dev = 0;
+    QMG_HIP_CHECK(hipGetDevice(&dev));
+    NormWorkspace& ws = g_norm_ws;
+    if (ws.device != dev || ws.cap < (size_t)nparts * nrhs) {
+      if (ws.part && ws.device == dev) QMG_HIP_CHECK(hipFree(ws.part));   // (synchronises: no launch still writes the old buffer)
+      ws.part = nullptr; ws.cap = 0;
+      QMG_HIP_CHECK(hipMalloc((void**)&ws.part, sizeof(double) * (size_t)nparts * nrhs));
+      ws.cap = (size_t)nparts * nrhs; ws.device = dev;
+    }
+    a.norm_part = ws.part;
+    dim3 grid(gx, gyp), block(BLOCK);
+    const bool pf = nc == 1 && nrhs > 1 && g_pair_prefetch;   // (nc = 2: the prefetch costs 3 %, tools/apply_norm_ab.py)
+#define QMG_NORM_LAUNCH(NC, ROWS, PF) k_stencil_pair<double, NC, ROWS, true, true, true, PF><<<grid, block, smem, st>>>(a);
+    if (nc == 1) {
+      if (rows == 2) { if (pf) { QMG_NORM_LAUNCH(1, 2, true) } else { QMG_NORM_LAUNCH(1, 2, false) } }
+      else { if (pf) { QMG_NORM_LAUNCH(1, 1, true) } else { QMG_NORM_LAUNCH(1, 1, false) } }
+    } else { if (rows == 2) { QMG_NORM_LAUNCH(2, 2, false) } else { QMG_NORM_LAUNCH(2, 1, false) } }
+#undef QMG_NORM_LAUNCH
+    QMG_LAUNCH_CHECK();
+    k_apply_norm_final<<<nrhs, BLOCK, 0, st>>>(ws.part, nparts, nrhs, norms_dev);
+    QMG_LAUNCH_CHECK();
+    return QMG_SUCCESS;
+  }
 
   // fp32: the one-site-per-lane-group kernel is the faster one (4096^2 Wilson: 0.573 ms against 0.592 ms for the paired
   // kernel, profiles/r02_kernel_rooflines.json: half the bytes per site leave the paired kernel's longer dependent chain
@@ -1272,11 +1402,17 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       case 2: k_stencil_pair<T, NC, ROWS, false, true><<<grid, block, 0, st>>>(a); break;     \
       default: k_stencil_pair<T, NC, ROWS, true, true><<<grid, block, 0, st>>>(a); break;     \
     }
+    // staggered-type batches (nc = 1, fp64, default non-temporal policy): the variant that requests system k+1 ahead of system
+    // k's arithmetic -- 4096^2, 8 systems: 1.04 -> 0.90 ms; at nc = 2 it loses 3 % (tools/apply_norm_ab.py), so not there
+    const bool pf = nc == 1 && !vec32 && a.nrhs > 1 && g_pair_prefetch && (g_stencil_nt & 3) == 3;
 #define QMG_PAIR_LAUNCH(NC, ROWS) if (vec32) { QMG_PAIR_LAUNCH_T(float, NC, ROWS) } else { QMG_PAIR_LAUNCH_T(double, NC, ROWS) }
-    if (nc == 1) { if (rows == 4) { QMG_PAIR_LAUNCH(1, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(1, 2) } else { QMG_PAIR_LAUNCH(1, 1) } }
+#define QMG_PAIR_LAUNCH_PF(ROWS) k_stencil_pair<double, 1, ROWS, true, true, false, true><<<grid, block, 0, st>>>(a);
+    if (pf) { if (rows == 4) { QMG_PAIR_LAUNCH_PF(4) } else if (rows == 2) { QMG_PAIR_LAUNCH_PF(2) } else { QMG_PAIR_LAUNCH_PF(1) } }
+    else if (nc == 1) { if (rows == 4) { QMG_PAIR_LAUNCH(1, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(1, 2) } else { QMG_PAIR_LAUNCH(1, 1) } }
     if (nc == 2) { if (rows == 4) { QMG_PAIR_LAUNCH(2, 4) } else if (rows == 2) { QMG_PAIR_LAUNCH(2, 2) } else { QMG_PAIR_LAUNCH(2, 1) } }
     if (nc == 4) { if (rows >= 2) { QMG_PAIR_LAUNCH(4, 2) } else { QMG_PAIR_LAUNCH(4, 1) } }
 #undef QMG_PAIR_LAUNCH
+#undef QMG_PAIR_LAUNCH_PF
 #undef QMG_PAIR_LAUNCH_T
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
