@@ -358,6 +358,7 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
  * beyond summation order.  Unknown keys return QMG_ERR_INVALID.
  *   "stencil_nt"    bit 0: non-temporal loads of the stencil matrices, bit 1: non-temporal stores, nc <= 4 kernels (3)
  *   "stencil_pair"  0: one site per lane group (kernel A); 1 / 2: both parities of a column on 1 / 2 rows per lane group (2)
+ *   "pair_prefetch" 1: fp64 batches with nc = 1 request system k+1's right-hand side ahead of system k's arithmetic (1)
  *   "stencil_rows"  cap on gridDim.y of the stencil kernels, 0 = one block row per lattice row (0)
  *   "stencil_mfma"  1: multi-rhs coarse applies (nc in 8,12,16,24,32; >= 4-5 systems) on the f64 matrix cores, 2-MFMA
  *                   packing for <= 8 systems; 2: plain 4-MFMA products; 0: vector-FMA kernel B only (1)

@@ -107,3 +107,29 @@ def test_apply_norm2_refusals():
             with pytest.raises(qmg.QmgError):   # more than 16 systems
                 qmg.stencil_apply_norm2(gd, w, v, ol.P_ALL | ol.P_ZERO, 17, vol)
         assert np.array_equal(w.to_host(), before)
+
+
+@pytest.mark.parametrize("Lx,Ly,nrhs", [(12, 6, 3), (1030, 4, 8), (64, 12, 16), (20, 3 * 2, 2)])
+def test_next_system_prefetch_changes_no_byte(Lx, Ly, nrhs):
+    """Kernel A2's prefetch of system k+1 (nc = 1 batches, tuning key "pair_prefetch") is a scheduling change only."""
+    vol = Lx * Ly
+    stride = vol + 2
+    clover, hopping, shifts = operator(Lx, Ly, 1, 11)
+    gd = qmg.make_desc(Lx, Ly, 1, D(clover), D(hopping), *shifts)
+    rhs = D(cs.gaussian_cvec(stride * nrhs, 12))
+    lhs0 = cs.gaussian_cvec(stride * nrhs, 13)
+    out = {}
+    try:
+        for pf in (0, 1):
+            qmg.set_tuning("pair_prefetch", pf)
+            for pieces in (ol.P_ALL | ol.P_ZERO, ol.P_ALL):
+                a, b = D(lhs0), D(lhs0)
+                qmg.stencil_apply(gd, a, rhs, pieces, nrhs, stride)
+                n = qmg.stencil_apply_norm2(gd, b, rhs, pieces, nrhs, stride)
+                out[pf, pieces] = (a.to_host(), b.to_host(), n)
+    finally:
+        qmg.set_tuning("pair_prefetch", 1)
+    for pieces in (ol.P_ALL | ol.P_ZERO, ol.P_ALL):
+        for i in range(3):
+            assert np.array_equal(out[0, pieces][i], out[1, pieces][i])
+        assert np.array_equal(out[0, pieces][0], out[0, pieces][1])
