@@ -20,7 +20,12 @@ SETUP_ONLY = ("k_probe_scatter", "k_unit_probe", "k_chol_store", "k_gaussian", "
 rows = []
 with open(f) as fh:
     for r in csv.DictReader(fh):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        name = r["Kernel_Name"]
+        # the stencil / transfer kernels serve every level: tell the levels apart by the launch grid (in blocks)
+        if any(k in name for k in ("k_stencil", "k_restrict", "k_prolong", "k_wilson")) and "Grid_Size_X" in r:
+            wx = max(1, int(r.get("Workgroup_Size_X", 1) or 1))
+            name = name.split("(")[0] + " grid=%dx%d" % (int(r["Grid_Size_X"]) // wx, int(r.get("Grid_Size_Y", 1) or 1))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 last_setup = max((i for i, r in enumerate(rows) if any(k in r[2] for k in SETUP_ONLY)), default=-1)
 solve = rows[last_setup + 1:]
@@ -44,7 +49,7 @@ def summarise(rs):
     top = sorted(per.items(), key=lambda kv: -kv[1][1])
     return {"wall_ms": wall / 1e6, "gpu_busy_ms": busy / 1e6, "idle_frac": 1.0 - busy / wall, "launches": len(rs),
             "avg_gap_us": (wall - busy) / 1e3 / max(1, len(rs) - 1),
-            "kernels": [{"kernel": k, "calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3, "pct_of_wall": 100.0 * v[1] / wall} for k, v in top[:16]]}
+            "kernels": [{"kernel": k, "calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3, "pct_of_wall": 100.0 * v[1] / wall} for k, v in top[:24]]}
 
 
 out = {"trace": os.path.basename(f), "setup": summarise(rows[:last_setup + 1]), "solve": summarise(solve)}
