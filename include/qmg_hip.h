@@ -352,6 +352,14 @@ int qmg_comm_emulate_end(void);
 int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
                             const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows,
                             void* stream);
+/* The hops of the RIGHT-BLOCK-JACOBI Wilson stencil (stencil_2d.h:1556-1581, H'_mu(x) = H_mu(x) . cinv(x + mu)) from the links, for
+ * a cinv that is `hop_scale` times the identity at every site (real mass, no eo / dof shift; hop_scale = the [0][0] entry
+ * qmg_build_rbjacobi left in cinv): 128 instead of 320 B per written site for the D'_eo / D'_oe of a Schur-complement apply.
+ * pieces: every hop of the processed parities and nothing else (QMG_ERR_UNSUPPORTED otherwise).  fp64: bit for bit the stored
+ * right-block-Jacobi hopping through the site kernel. */
+int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, double hop_scale, void* lhs,
+                           const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride,
+                           unsigned mask, int rows, void* stream);
 
 /* ---------------- tuning hooks (not part of the reference surface) ---------------- */
 /* Dispatch / codegen knobs, all with the defaults the measurements in profiles/ chose; results never depend on them

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_norm2",
-    "qmg_wilson_apply_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
+    "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -513,6 +513,13 @@ def wilson_apply_direct(dtype, desc, gauge, lhs, rhs, pieces, w=1.0, nrhs=1, vec
     check(lib().qmg_wilson_apply_direct(dtype, C.byref(desc), _vp(gauge), desc.Ly if gauge_Ly is None else gauge_Ly, y0, C.c_double(w), _vp(lhs), _vp(rhs),
                                         _vp(halo_lo), _vp(halo_hi), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_size_t(halo_stride), C.c_uint(mask), rows,
                                         stream), "qmg_wilson_apply_direct")
+
+
+def wilson_hops_direct(dtype, desc, gauge, lhs, rhs, pieces, w, hop_scale, nrhs=1, vec_stride=0, mask=1, gauge_Ly=None, y0=0, halo_lo=None, halo_hi=None,
+                       halo_stride=0, rows=0, stream=None):
+    check(lib().qmg_wilson_hops_direct(dtype, C.byref(desc), _vp(gauge), desc.Ly if gauge_Ly is None else gauge_Ly, y0, C.c_double(w), C.c_double(hop_scale),
+                                       _vp(lhs), _vp(rhs), _vp(halo_lo), _vp(halo_hi), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_size_t(halo_stride),
+                                       C.c_uint(mask), rows, stream), "qmg_wilson_hops_direct")
 
 
 def comm_set_distributed_reductions(on):

@@ -17,6 +17,10 @@
 // neighbours' (opposite parity).  Load phase as raw registers behind a scheduling barrier, as in qmg_site.hip.
 // Piece sets served: clover + all hops (+ shifts) of the processed parities (apply_M and its one-parity forms) and hops
 // only (D_eo / D_oe); anything else returns QMG_ERR_UNSUPPORTED and the caller uses the stored stencil.
+// The hops of the RIGHT-BLOCK-JACOBI stencil (stencil_2d.h:1556-1581: H'_mu(x) = H_mu(x) . cinv(x + mu)) come from the links
+// too when cinv is one real number times the identity -- Wilson with a real mass and no eo / dof shift: cinv = 1 / (2w + m) --:
+// every entry is then the stored entry times that number (SHAPE 3, qmg_wilson_hops_direct), which is exactly what the build's
+// 2x2 product leaves in memory, so the Schur-complement applies of the K-cycle stream 128 instead of 320 B per written site.
 // y-slabs: the links are indexed on the GLOBAL lattice (replicated, 32 B/site), only the right-hand side's rows
 // -1 / Ly come from halo buffers.
 #include <type_traits>
@@ -39,6 +43,7 @@ struct WilsonArgs {
   long vec_stride;
   int par_first, par_count, nrows;
   double w;
+  double hop_scale;        // SHAPE 3: every hop entry times this (the right-block-Jacobi hops of a uniform cinv)
   double shift[2], eo_shift[2], dof_shift[2];
   int ridx[16];
   const void* halo_lo;
@@ -73,8 +78,8 @@ template <typename V> __device__ __forceinline__ V gld_nt(const gchar* base, uns
 // the four hop matrices' entries [row][col] for column c from the links (k_wilson_fill's multiplications, qmg_fill.hip)
 template <typename R>
 struct HopCol { R m0x, m0y, m1x, m1y; };   // entry (row 0, col c) and (row 1, col c)
-template <typename R>
-__device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw) {
+template <typename R, bool SCALED>
+__device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw, R sc) {
   // (ux, uy) = the link (already conjugated for the backward directions)
   const R dx = hw * ux, dy = hw * uy;                 // diagonal entry: -w/2 U
   const R h = (R)0.5;
@@ -89,11 +94,13 @@ __device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw) {
   }
   if (c == 0) { o.m0x = dx; o.m0y = dy; o.m1x = ox; o.m1y = oy; }
   else { o.m0x = ox; o.m0y = oy; o.m1x = dx; o.m1y = dy; }
+  if (SCALED) { o.m0x *= sc; o.m0y *= sc; o.m1x *= sc; o.m1y *= sc; }   // the stored entry times cinv (k_rb_hopping's product)
   return o;
 }
 
 // One site's (fp64: one site's column c0) result from its five right-hand-side chunks xr = {+x, +y, -x, -y, own} and its four
 // links (backward ones already conjugated), then the store.  The order of operations is kernel S's (qmg_site.hip).
+// SHAPE 1: clover + hops (+ shift); 2: hops; 3: hops scaled by a.hop_scale.
 template <typename T, int SHAPE>
 __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4], const T (&ly)[4], T hw, T cw, bool do_shift, bool do_zero, int p, int c0,
                                             const WilsonArgs& a, gchar* dst_chunk) {
@@ -120,7 +127,7 @@ __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4]
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       comp(xr[d], vx, vy);
-      const HopCol<R> m = hop_col<R>(d, c, lx[d], ly[d], hw);
+      const HopCol<R> m = hop_col<R, SHAPE == 3>(d, c, lx[d], ly[d], hw, (R)a.hop_scale);
       fmac2w<R>(ax[cc][0], ay[cc][0], m.m0x, m.m0y, vx, vy);
       fmac2w<R>(ax[cc][1], ay[cc][1], m.m1x, m.m1y, vx, vy);
     }
@@ -153,7 +160,8 @@ __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4]
   }
 }
 
-// T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only.
+// T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only;
+// 3: hops only, entries scaled (right-block-Jacobi).
 template <typename T, int SHAPE, bool ZERO, bool BATCH>
 __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
 template <typename T, bool BATCH>
 static void launch_wilson_b(const WilsonArgs& a, int shape, bool zero, dim3 grid, hipStream_t st) {
   if (shape == 1) { if (zero) k_wilson_direct<T, 1, true, BATCH><<<grid, BLOCK, 0, st>>>(a); else k_wilson_direct<T, 1, false, BATCH><<<grid, BLOCK, 0, st>>>(a); }
+  else if (shape == 3) { if (zero) k_wilson_direct<T, 3, true, BATCH><<<grid, BLOCK, 0, st>>>(a); else k_wilson_direct<T, 3, false, BATCH><<<grid, BLOCK, 0, st>>>(a); }
   else { if (zero) k_wilson_direct<T, 2, true, BATCH><<<grid, BLOCK, 0, st>>>(a); else k_wilson_direct<T, 2, false, BATCH><<<grid, BLOCK, 0, st>>>(a); }
 }
 
@@ -334,7 +343,24 @@ static void launch_wilson_b(const WilsonArgs& a, int shape, bool zero, dim3 grid
 
 using namespace qmg;
 
+static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, bool scaled, double hop_scale,
+                              void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride,
+                              size_t halo_stride, unsigned mask, int rows, void* stream);
+
 extern "C" {
+
+// The hops of the right-block-Jacobi Wilson stencil from the links: lhs (+)= pieces(H') rhs with H'_mu(x) = H_mu(x) * hop_scale, for
+// a cinv that is hop_scale times the identity at every site (real mass, no eo / dof shift: hop_scale = the [0][0] entry qmg_build_rbjacobi
+// left in cinv).  `pieces`: all four hops of the processed parities and nothing else (+ the zero bits); otherwise QMG_ERR_UNSUPPORTED.
+// In fp64 the result is bit for bit qmg_stencil_apply on the stored right-block-Jacobi hopping through the site kernel.
+// Arguments as qmg_wilson_apply_direct.
+int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, double hop_scale, void* lhs,
+                           const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride,
+                           unsigned mask, int rows, void* stream) {
+  if (pieces & (QMG_P_CLOVER | QMG_P_SHIFT)) return QMG_ERR_UNSUPPORTED;
+  return wilson_direct_impl(dtype, d, gauge, gauge_Ly, y0, wilson_coeff, true, hop_scale, lhs, rhs, halo_lo, halo_hi, pieces, nrhs, vec_stride, halo_stride, mask,
+                            rows, stream);
+}
 
 // lhs (+)= pieces(M_Wilson) rhs from the gauge links; d carries the vectors' lattice (Lx, Ly; nc must be 2) and the shifts,
 // its clover / hopping pointers are ignored.  gauge: [2][Lx * gauge_Ly] links in `dtype` on the lattice Lx x gauge_Ly, of
@@ -345,6 +371,15 @@ extern "C" {
 int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
                             const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask, int rows,
                             void* stream) {
+  return wilson_direct_impl(dtype, d, gauge, gauge_Ly, y0, wilson_coeff, false, 1.0, lhs, rhs, halo_lo, halo_hi, pieces, nrhs, vec_stride, halo_stride, mask, rows,
+                            stream);
+}
+
+}  // extern "C"
+
+static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, bool scaled, double hop_scale,
+                              void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride,
+                              size_t halo_stride, unsigned mask, int rows, void* stream) {
   if (!valid_dtype(dtype) || !d || !gauge || !lhs || !rhs || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || !valid_lattice(d->Lx, gauge_Ly) || y0 < 0 || (y0 & 1) || y0 + d->Ly > gauge_Ly) return QMG_ERR_INVALID;
   if (d->nc != 2) return QMG_ERR_UNSUPPORTED;
@@ -355,7 +390,7 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
   a.gauge = gauge; a.lhs = lhs; a.rhs = rhs;
   a.hr = d->Lx / 2; a.Ly = d->Ly; a.gLy = gauge_Ly; a.gy0 = y0;
   a.half_vol = (long)a.hr * d->Ly; a.ghalf_vol = (long)a.hr * gauge_Ly;
-  a.pieces = pieces; a.vec_stride = (long)vec_stride; a.w = wilson_coeff;
+  a.pieces = pieces; a.vec_stride = (long)vec_stride; a.w = wilson_coeff; a.hop_scale = hop_scale;
   a.nrhs = 0;
   for (int k = 0; k < 16; k++) a.ridx[k] = 0;
   for (int k = 0; k < nrhs; k++)
@@ -383,8 +418,9 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
     sh[q] = (hm == 0xFu) ? (cl ? 1 : (shf ? 0 : 2)) : 0;
     if (!((pieces >> (12 + p)) & 1u)) zero = false;
   }
-  const int shape = (a.par_count == 2 && sh[0] != sh[1]) ? 0 : sh[0];
-  if (shape == 0) return QMG_ERR_UNSUPPORTED;
+  int shape = (a.par_count == 2 && sh[0] != sh[1]) ? 0 : sh[0];
+  if (shape == 0 || (scaled && shape != 2)) return QMG_ERR_UNSUPPORTED;
+  if (scaled) shape = 3;
   if (lhs == rhs && (shape == 1 || a.par_count == 2)) return QMG_ERR_INVALID;
   const int lps = dtype == QMG_C64 ? 2 : 1;
   const long lanes = (long)a.hr * lps;
@@ -407,5 +443,3 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
-
-}  // extern "C"

@@ -71,7 +71,13 @@ struct Stencil2D {
     d.shift[0] = s.real(); d.shift[1] = s.imag();
     d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
     d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
-    if (qmg::slab().on) { launch_slab(d, pieces, lhs, rhs, direct_usable(cl, ho)); return; }
+    const double rbj_sc = rbj_direct_usable(cl, ho, pieces) ? direct.rbj_scale : 0.0;
+    if (qmg::slab().on) { launch_slab(d, pieces, lhs, rhs, direct_usable(cl, ho), rbj_sc); return; }
+    if (rbj_sc != 0.0) {           // D'_eo / D'_oe of the right-block-Jacobi Wilson stencil: the links times one number
+      const int rc = qmg_wilson_hops_direct(QMG_C64, &d, direct.gauge, d.Ly, 0, direct.w, rbj_sc, lhs, rhs, 0, 0, pieces, 1, 0, 0, 1u, 0, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_hops_direct"); return; }
+    }
     if (direct_usable(cl, ho)) {   // straight from the links where that serves the piece set
       const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, 1, 0, 0, 1u, 0, qmg::current_stream());
       if (rc == QMG_SUCCESS) return;
@@ -117,6 +123,8 @@ struct Stencil2D {
   // QMG_WILSON_DIRECT=0 in the environment turns it off.
   struct DirectLinks {
     complex<double>* gauge; void* gauge32; double w; bool on;
+    // right-block-Jacobi hops from the links too (qmg_wilson_hops_direct): cinv = rbj_scale x identity at every site, 0 = not so
+    double rbj_scale;
   } direct;
   // y-slab mode (qmg::slab()): the halo rows of the right-hand side of an apply, [parity][Lx/2][nc] each
   complex<double>*slab_halo_lo, *slab_halo_hi;
@@ -128,7 +136,7 @@ struct Stencil2D {
   // which parities of the right-hand side the hops of `pieces` read: D_eo (even sites written) reads odd rows, D_oe even rows
   static unsigned halo_parities(unsigned pieces) { return ((pieces & QMG_P_EO) ? 2u : 0u) | ((pieces & QMG_P_OE) ? 1u : 0u); }
   // one system on a slab: exchange the halo rows of rhs with the neighbouring ranks, then apply with them
-  void launch_slab(const qmg_stencil_desc& d, unsigned pieces, complex<double>* lhs, complex<double>* rhs, bool original_arrays) {
+  void launch_slab(const qmg_stencil_desc& d, unsigned pieces, complex<double>* lhs, complex<double>* rhs, bool original_arrays, double rbj_scale = 0.0) {
     if (!slab_halos()) { std::cout << "[QMG-ERROR]: no memory for the halo rows\n"; return; }
     const size_t hs = (size_t)d.Lx * d.nc;
     void* st = qmg::current_stream();
@@ -136,6 +144,12 @@ struct Stencil2D {
     // rows: 0 = all rows after the exchange; with more than one rank the nc = 2 kernels run the interior rows WHILE the halo rows travel
     // (exchange on a second stream behind an event), then the two boundary rows -- what SlabWilson2D does (slab.hpp)
     auto apply_rows = [&](int rows) -> bool {
+      if (rbj_scale != 0.0) {               // right-block-Jacobi hops from the links
+        const int rc = qmg_wilson_hops_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, rbj_scale, lhs, rhs, slab_halo_lo,
+                                              slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st);
+        if (rc == QMG_SUCCESS) return true;
+        if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) return qmg::ok(rc, "qmg_wilson_hops_direct");
+      }
       if (original_arrays && direct.on) {   // Wilson straight from the (global, replicated) links
         const int rc = qmg_wilson_apply_direct(QMG_C64, &d, direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, lhs, rhs, slab_halo_lo,
                                                slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st);
@@ -173,8 +187,14 @@ struct Stencil2D {
   bool direct_usable(const complex<double>* cl, const complex<double>* ho) const {
     return direct.on && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
   }
+  // the hops of the right-block-Jacobi stencil, alone, while that stencil is the built one (swapped in or not)
+  bool rbj_direct_usable(const complex<double>* cl, const complex<double>* ho, unsigned pieces) const {
+    return direct.on && direct.rbj_scale != 0.0 && built_rbjacobi && cl == 0 && ho != 0 && ho == rbjacobi_hopping_in_use() && !swap_dagger && !swap_rbj_dagger &&
+           !(pieces & (QMG_P_CLOVER | QMG_P_SHIFT));
+  }
   void set_direct_links(const complex<double>* gauge_links, double w) {   // copies the links (the caller's array may change)
     static const bool enabled = !(getenv("QMG_WILSON_DIRECT") && atoi(getenv("QMG_WILSON_DIRECT")) == 0);
+    direct.rbj_scale = 0.0;   // (a right-block-Jacobi stencil of the old links is dropped by the caller)
     const size_t n = (size_t)2 * lat->get_volume() * (qmg::slab().on ? qmg::slab().world : 1);   // a slab keeps the links of the WHOLE lattice (32 B/site)
     if (!enabled || lat->get_nc() != 2) { direct.on = false; return; }
     if (!direct.gauge) direct.gauge = allocate_vector<complex<double>>(n);
@@ -187,7 +207,7 @@ struct Stencil2D {
   void drop_direct_links() {
     if (direct.gauge) deallocate_vector(&direct.gauge);
     if (direct.gauge32) { qmg_free(direct.gauge32); direct.gauge32 = 0; }
-    direct.on = false;
+    direct.on = false; direct.rbj_scale = 0.0;
   }
 
   bool built_dagger;
@@ -220,7 +240,7 @@ struct Stencil2D {
     eo_cvector = 0;
     f32_matrices = false; clover32 = hopping32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
-    direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false;
+    direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false; direct.rbj_scale = 0.0;
     slab_halo_lo = slab_halo_hi = 0;
     slab_comm_stream = slab_ev_rhs = slab_ev_halo = 0;
     f32.clover16 = f32.hopping16 = f32.rbj_hopping16 = 0; f32.half_on = false;
@@ -462,6 +482,12 @@ struct Stencil2D {
         if (rc == QMG_SUCCESS) return;
         if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
       }
+      if (set == QMG_ARR_RBJ_HOPPING && rbj_direct_usable(0, rbjacobi_hopping_in_use(), pieces) && (!f || direct.gauge32)) {
+        const int rc = qmg_wilson_hops_direct(dt, &d, f ? direct.gauge32 : (void*)direct.gauge, d.Ly * qmg::slab().world, qmg::slab().rank * d.Ly, direct.w, direct.rbj_scale,
+                                              lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st);
+        if (rc == QMG_SUCCESS) return;
+        if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_hops_direct"); return; }
+      }
       if (f && f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices (nc = 2), fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
@@ -483,6 +509,12 @@ struct Stencil2D {
                                              d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, nrhs, stride, 0, mask, 0, qmg::current_stream());
       if (rc == QMG_SUCCESS) return;
       if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
+    }
+    if (set == QMG_ARR_RBJ_HOPPING && rbj_direct_usable(0, rbjacobi_hopping_in_use(), pieces) && (sizeof(T) == sizeof(double) || direct.gauge32)) {
+      const int rc = qmg_wilson_hops_direct(sizeof(T) == sizeof(float) ? QMG_C32 : QMG_C64, &d, sizeof(T) == sizeof(float) ? direct.gauge32 : (void*)direct.gauge,
+                                            d.Ly, 0, direct.w, direct.rbj_scale, lhs, rhs, 0, 0, pieces, nrhs, stride, 0, mask, 0, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_hops_direct"); return; }
     }
     if (sizeof(T) == sizeof(float)) {
       if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
@@ -662,6 +694,15 @@ struct Stencil2D {
     if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
     if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
     built_rbjacobi = true;
+    // Wilson from the links (set_direct_links) with a real mass and no eo / dof shift: cinv is ONE real number times the identity
+    // at every site, and the right-block-Jacobi hops are the stored hops times it -- take the number the build left in cinv
+    direct.rbj_scale = 0.0;
+    static const bool rbj_direct_wanted = !(getenv("QMG_WILSON_DIRECT_RBJ") && atoi(getenv("QMG_WILSON_DIRECT_RBJ")) == 0);
+    if (rbj_direct_wanted && direct.on && rbjacobi_hopping && lat->get_nc() == 2 && shift.imag() == 0.0 && eo_shift == 0.0 && dof_shift == 0.0 && !swap_dagger && !swap_rbj_dagger) {
+      const std::vector<complex<double>> c = qmg::to_host(rbjacobi_cinv, (size_t)4);
+      const double expect = 1.0 / (2.0 * direct.w + shift.real());
+      if (c[0] == c[3] && c[0].imag() == 0.0 && c[1] == 0.0 && c[2] == 0.0 && std::abs(c[0].real() - expect) <= 1e-14 * std::abs(expect)) direct.rbj_scale = c[0].real();
+    }
   }
 
   bool perform_swap_rbjacobi() {   // :1604-1639

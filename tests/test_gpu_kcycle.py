@@ -238,3 +238,25 @@ def test_n22_rank_sharded_setup_through_rccl(golden_dir):
     pick = lambda out: (re.search(r"Multigrid converged in (\d+) iterations with alleged tolerance ([-\d.e+]+)", out.stdout).groups(),
                         re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
     assert pick(plain) == pick(forced)
+
+
+@pytest.mark.parametrize("extra", [[], ["nrhs=2"], ["nrhs=2", "f32"]])
+def test_rbjacobi_hops_from_the_links_reproduce_the_stored_stencil_solve(golden_dir, extra):
+    """Schur-complement K-cycle (n22 schur) with the level-0 right-block-Jacobi hops applied from the links x cinv (qmg_wilson_hops_direct,
+    the default) against the same solve streaming the built right-block-Jacobi hopping (QMG_WILSON_DIRECT_RBJ=0): in fp64 the applies are
+    bit-identical, so every printed iteration count and residual must be the same text; the fp32 K-cycle (different rounding of the fp32
+    entries) must converge in the same number of outer iterations +- 1."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    cmd = [os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "2", "1", gauge_file, "64", "schur"] + extra
+    outs = {}
+    for flag in ("1", "0"):
+        p = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", QMG_WILSON_DIRECT_RBJ=flag), capture_output=True, text=True, timeout=150)
+        assert p.returncode == 0 and "[QMG-ERROR]" not in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+        outs[flag] = [l for l in p.stdout.splitlines() if "TIMING" not in l]
+    if "f32" not in extra:
+        assert outs["1"] == outs["0"]
+    else:
+        rows = {f: re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", "\n".join(o)) for f, o in outs.items()}
+        assert len(rows["1"]) == 2 and len(rows["0"]) == 2
+        for a, b in zip(rows["1"], rows["0"]):
+            assert abs(int(a[1]) - int(b[1])) <= 1 and float(a[3]) <= 1.05e-10

@@ -133,3 +133,54 @@ def test_direct_apply_on_slabs_reads_the_global_links(R):
         got = out.to_host()
         for k in range(nrhs):
             assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], y0)), (R, r, k)
+
+
+RBJ_SERVED = [P.P_EO | P.P_ZERO_E, P.P_OE | P.P_ZERO_O, P.P_EO, P.P_OE, P.P_HOPPING | P.P_ZERO, P.P_HOPPING]
+
+
+@pytest.mark.parametrize("Lx,Ly,mass", [(16, 16, -0.07), (24, 10, 0.3), (130, 6, -0.2)])
+def test_rbjacobi_hops_from_the_links_are_bit_identical_to_the_built_stencil(Lx, Ly, mass):
+    """Right-block-Jacobi Wilson (stencil_2d.h:1452-1601): cinv = 1 / (2w + m) times the identity, so H' = H * cinv(x + mu) has the stored
+    hop entries times ONE number -- qmg_wilson_hops_direct forms them from the links with that number read back from the built cinv."""
+    n, vol = 2 * Lx * Ly, Lx * Ly
+    g = D(gauge(Lx, Ly, 5))
+    cl, hp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
+    w = 0.9
+    qmg.wilson_fill(cl, hp, g, Lx, Ly, w)
+    d = qmg.make_desc(Lx, Ly, 2, cl, hp, mass)
+    cinv, rcl, rhp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
+    qmg.build_rbjacobi(cinv, rcl, rhp, d)
+    ci = cinv.to_host().reshape(vol, 4)
+    scale = ci[0, 0].real
+    assert np.all(ci[:, 0] == ci[0, 0]) and np.all(ci[:, 3] == ci[0, 0]) and np.all(ci[:, 1] == 0) and np.all(ci[:, 2] == 0) and ci[0, 0].imag == 0
+    assert abs(scale - 1.0 / (2 * w + mass)) < 1e-15
+    drb = qmg.make_desc(Lx, Ly, 2, None, rhp)
+    nrhs, mask = 3, 0b101
+    x, l0 = cs.gaussian_cvec(n * nrhs, 1), cs.gaussian_cvec(n * nrhs, 2)
+    dx = D(x)
+    for pieces in RBJ_SERVED:
+        want, got = D(l0), D(l0)
+        qmg.stencil_apply_t(qmg.C64, drb, want, dx, pieces, nrhs, n, mask)
+        qmg.wilson_hops_direct(qmg.C64, drb, g, got, dx, pieces, w, scale, nrhs, n, mask)
+        assert np.array_equal(got.to_host(), want.to_host()), hex(pieces)
+        want1, got1 = D(l0[:n]), D(l0[:n])
+        qmg.stencil_apply(drb, want1, dx, pieces)
+        qmg.wilson_hops_direct(qmg.C64, drb, g, got1, dx, pieces, w, scale)
+        assert np.array_equal(got1.to_host(), want1.to_host()), hex(pieces)
+    # in place (the Schur complement's second hop, stencil_2d.h:1904) and fp32
+    a, b = D(x[:n]), D(x[:n])
+    qmg.stencil_apply(drb, a, a, P.P_EO | P.P_ZERO_E)
+    qmg.wilson_hops_direct(qmg.C64, drb, g, b, b, P.P_EO | P.P_ZERO_E, w, scale)
+    assert np.array_equal(a.to_host(), b.to_host())
+    g32 = D(g.to_host().astype(np.complex64))
+    out32 = qmg.DeviceArray(n, np.complex64)
+    qmg.wilson_hops_direct(qmg.C32, drb, g32, out32, D(x[:n].astype(np.complex64)), P.P_HOPPING | P.P_ZERO, w, scale)
+    ref = qmg.DeviceArray(n)
+    qmg.stencil_apply(drb, ref, dx, P.P_HOPPING | P.P_ZERO)
+    assert cs.rel_l2(out32.to_host().astype(np.complex128), ref.to_host()) < 2e-6
+    # what it does not serve
+    import ctypes as C
+    def call(pieces):
+        return qmg.lib().qmg_wilson_hops_direct(qmg.C64, C.byref(drb), C.c_void_p(g.ptr), Ly, 0, C.c_double(w), C.c_double(scale), C.c_void_p(got.ptr), C.c_void_p(dx.ptr),
+                                                None, None, C.c_uint(pieces), 1, C.c_size_t(0), C.c_size_t(0), C.c_uint(1), 0, None)
+    assert call(P.P_ALL | P.P_ZERO) == 3 and call(P.P_HOPPING | P.P_SHIFT | P.P_ZERO) == 3 and call(P.P_EO_XP1 | P.P_ZERO_E) == 3

@@ -25,8 +25,25 @@ for L in (4096, 2048):
         qmg.set_tuning("wilson_pair", pair)
         run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, FULL), 96 * vol, "L=%d fp64 from the links (kernel W%s), 96 B/site" % (L, "2: paired parities" if pair else ""))
     qmg.set_tuning("wilson_pair", 1)
-    run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, DEO), 80 * vol / 2, "L=%d fp64 from the links, D_eo, 80 B/site" % L)
-    del cl, hp
+    run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, DEO), 128 * vol / 2, "L=%d fp64 from the links, D_eo, 128 B per written site" % L)
+    # the right-block-Jacobi hops (the Schur complement's D'_eo): stored (kernel S, 320 B per written site) against links x cinv
+    cinv, rcl, rhp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
+    qmg.build_rbjacobi(cinv, rcl, rhp, d)
+    scale = cinv.to_host()[0].real
+    del cinv, rcl
+    drb = qmg.make_desc(L, L, 2, None, rhp)
+    run(lambda: qmg.stencil_apply(drb, l, r, DEO), 320 * vol / 2, "L=%d fp64 rbj D'_eo stored (kernel S), 320 B per written site" % L)
+    run(lambda: qmg.wilson_hops_direct(qmg.C64, drb, g, l, r, DEO, 1.0, scale), 128 * vol / 2, "L=%d fp64 rbj D'_eo from the links, 128 B per written site" % L)
+    r32, l32 = qmg.DeviceArray(2 * vol, np.complex64), qmg.DeviceArray(2 * vol, np.complex64)
+    qmg.convert(r32, qmg.C32, r, qmg.C64, 2 * vol)
+    h32 = qmg.DeviceArray(16 * vol, np.complex64); qmg.convert(h32, qmg.C32, rhp, qmg.C64, 16 * vol)
+    d32 = qmg.make_desc(L, L, 2, None, h32)
+    run(lambda: qmg.stencil_apply_t(qmg.C32, d32, l32, r32, DEO), 160 * vol / 2, "L=%d fp32 rbj D'_eo stored (kernel S), 160 B per written site" % L)
+    h16 = qmg.DeviceArray(16 * vol, np.float32); qmg.convert_to_c16(h16, rhp, qmg.C64, 16 * vol)
+    d16 = qmg.make_desc(L, L, 2, None, h16)
+    run(lambda: qmg.stencil_apply_h16(d16, l32, r32, DEO), 96 * vol / 2, "L=%d 16-bit rbj D'_eo stored (kernel S), 96 B per written site" % L)
+    run(lambda: qmg.wilson_hops_direct(qmg.C32, drb, g32, l32, r32, DEO, 1.0, scale), 64 * vol / 2, "L=%d fp32 rbj D'_eo from the links, 64 B per written site" % L)
+    del cl, hp, rhp, h32, h16, r32, l32
     r32, l32 = qmg.DeviceArray(2 * vol, np.complex64), qmg.DeviceArray(2 * vol, np.complex64)
     qmg.convert(r32, qmg.C32, r, qmg.C64, 2 * vol)
     for pair in (1, 0):
