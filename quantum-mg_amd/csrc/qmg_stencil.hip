@@ -448,17 +448,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
 #pragma unroll
       for (int w = 1; w < BLOCK / WAVE; w++) t += norm_sm[k * BLOCK + w * WAVE + lane];
       t = wave_sum(t);
-      if (lane == 0) a.norm_part[((long)blockIdx.y * gridDim.x + blockIdx.x) * a.nrhs + k] = t;
+      if (lane == 0) a.norm_part[(long)k * ((long)gridDim.y * gridDim.x) + (long)blockIdx.y * gridDim.x + blockIdx.x] = t;   // [system][block]
     }
   }
 }
 
-// the partials of system q (stride = systems), summed in a fixed order
-__global__ __launch_bounds__(BLOCK) void k_apply_norm_final(const double* __restrict__ part, long nparts, int stride, double* __restrict__ out) {
+// the partials of system q (contiguous: [system][block]), summed in a fixed order
+__global__ __launch_bounds__(BLOCK) void k_apply_norm_final(const double* __restrict__ part, long nparts, double* __restrict__ out) {
   __shared__ double sm[BLOCK / WAVE];
   const int q = blockIdx.x;
   double t = 0.0;
-  for (long i = threadIdx.x; i < nparts; i += BLOCK) t += part[i * stride + q];
+  for (long i = threadIdx.x; i < nparts; i += BLOCK) t += part[(long)q * nparts + i];
   t = wave_sum(t);
   if ((threadIdx.x & (WAVE - 1)) == 0) sm[threadIdx.x / WAVE] = t;
   __syncthreads();
@@ -1378,7 +1378,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     } else { if (rows == 2) { QMG_NORM_LAUNCH(2, 2, false) } else { QMG_NORM_LAUNCH(2, 1, false) } }
 #undef QMG_NORM_LAUNCH
     QMG_LAUNCH_CHECK();
-    k_apply_norm_final<<<nrhs, BLOCK, 0, st>>>(ws.part, nparts, nrhs, norms_dev);
+    k_apply_norm_final<<<nrhs, BLOCK, 0, st>>>(ws.part, nparts, norms_dev);
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
   }

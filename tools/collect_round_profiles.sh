@@ -17,6 +17,7 @@ python tools/bench_r02.py > $O/${TAG}_kernel_rooflines.json 2> $O/bench_r02.err
 echo kernels done
 python tools/site_kernel_ab.py > $O/${TAG}_site_kernel_ab.txt 2>&1
 python tools/apply_norm_ab.py > $O/${TAG}_apply_norm_ab.txt 2>&1
+bash tools/pmc_ab.sh tools/apply_norm_ab.py >> $O/${TAG}_apply_norm_ab.txt 2>&1
 bash tools/pmc_wilson_direct.sh > $O/${TAG}_wilson_direct_pmc.txt 2>&1
 python tools/wilson_direct_bench.py >> $O/${TAG}_wilson_direct_pmc.txt 2>&1
 echo ab done
