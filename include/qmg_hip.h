@@ -378,7 +378,8 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *   "site_block"    threads per block of the site kernel: 64, 128 or 256 (256); "site_gy": cap on its grid.y, 0 = rows (0);
  *                   "site_generic": 1 = its run-time-flag variant instead of the compile-time piece shapes (0)
  *   "mfma_vl"       kernel C: right-hand sides through an LDS slice (coalesced loads / stores) (1)
- *   "wilson_pair"   1: the full Wilson operator from the links through the paired-parity kernel W2 (csrc/qmg_wilson.hip) (1)
+ *   "wilson_pair"   the full Wilson operator from the links: 0 = one site per lane group (kernel W), 1 = both parities of a column
+ *                   (kernel W2), 2 = W2 on two rows per lane group for one system on an even run of rows, else as 1 (2)
  *   "xfer_pack"     1: complex<float> single-system restrict / prolong move two elements per lane (16-byte accesses) (1)
  *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
  *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);

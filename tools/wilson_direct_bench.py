@@ -21,10 +21,10 @@ for L in (4096, 2048):
     d = qmg.make_desc(L, L, 2, cl, hp, -0.07)
     r, l = qmg.DeviceArray(2 * vol), qmg.DeviceArray(2 * vol); qmg.gaussian(r, 2 * vol, 5)
     run(lambda: qmg.stencil_apply(d, l, r, FULL), 384 * vol, "L=%d fp64 stored stencil (kernel A), 384 B/site" % L)
-    for pair in (1, 0):
+    for pair in (2, 1, 0):
         qmg.set_tuning("wilson_pair", pair)
-        run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, FULL), 96 * vol, "L=%d fp64 from the links (kernel W%s), 96 B/site" % (L, "2: paired parities" if pair else ""))
-    qmg.set_tuning("wilson_pair", 1)
+        run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, FULL), 96 * vol, "L=%d fp64 from the links (kernel W%s), 96 B/site" % (L, ("", "2: paired parities", "2: paired parities x 2 rows")[pair]))
+    qmg.set_tuning("wilson_pair", 2)
     run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, l, r, DEO), 128 * vol / 2, "L=%d fp64 from the links, D_eo, 128 B per written site" % L)
     # the right-block-Jacobi hops (the Schur complement's D'_eo): stored (kernel S, 320 B per written site) against links x cinv
     cinv, rcl, rhp = qmg.DeviceArray(4 * vol), qmg.DeviceArray(4 * vol), qmg.DeviceArray(16 * vol)
@@ -46,10 +46,10 @@ for L in (4096, 2048):
     del cl, hp, rhp, h32, h16, r32, l32
     r32, l32 = qmg.DeviceArray(2 * vol, np.complex64), qmg.DeviceArray(2 * vol, np.complex64)
     qmg.convert(r32, qmg.C32, r, qmg.C64, 2 * vol)
-    for pair in (1, 0):
+    for pair in (2, 1, 0):
         qmg.set_tuning("wilson_pair", pair)
-        run(lambda: qmg.wilson_apply_direct(qmg.C32, d, g32, l32, r32, FULL), 48 * vol, "L=%d fp32 from the links%s, 48 B/site" % (L, " (paired)" if pair else ""))
-    qmg.set_tuning("wilson_pair", 1)
+        run(lambda: qmg.wilson_apply_direct(qmg.C32, d, g32, l32, r32, FULL), 48 * vol, "L=%d fp32 from the links%s, 48 B/site" % (L, ("", " (paired)", " (paired x 2 rows)")[pair]))
+    qmg.set_tuning("wilson_pair", 2)
     K = 8 if L == 2048 else 4
     rb, lb = qmg.DeviceArray(2 * vol * K), qmg.DeviceArray(2 * vol * K); qmg.gaussian(rb, 2 * vol * K, 6)
     run(lambda: qmg.wilson_apply_direct(qmg.C64, d, g, lb, rb, FULL, 1.0, K, 2 * vol, (1 << K) - 1), (32 + 64 * K) * vol, "L=%d fp64 from the links, %d systems" % (L, K))
