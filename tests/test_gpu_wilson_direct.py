@@ -184,3 +184,37 @@ def test_rbjacobi_hops_from_the_links_are_bit_identical_to_the_built_stencil(Lx,
         return qmg.lib().qmg_wilson_hops_direct(qmg.C64, C.byref(drb), C.c_void_p(g.ptr), Ly, 0, C.c_double(w), C.c_double(scale), C.c_void_p(got.ptr), C.c_void_p(dx.ptr),
                                                 None, None, C.c_uint(pieces), 1, C.c_size_t(0), C.c_size_t(0), C.c_uint(1), 0, None)
     assert call(P.P_ALL | P.P_ZERO) == 3 and call(P.P_HOPPING | P.P_SHIFT | P.P_ZERO) == 3 and call(P.P_EO_XP1 | P.P_ZERO_E) == 3
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_rbjacobi_hops_from_the_links_on_slabs(R):
+    """qmg_wilson_hops_direct on y-slabs (global links, halo rows of the right-hand side): bit for bit the rows of the single-domain call,
+    for D'_eo, D'_oe and both, all rows / interior + boundary rows."""
+    L, nrhs, w, scale = 32, 2, 1.0, 1.0 / (2.0 - 0.07)
+    n = 2 * L * L
+    g = D(gauge(L, L, 16))
+    d = qmg.make_desc(L, L, 2, None, None)
+    x = cs.gaussian_cvec(n * nrhs, 19)
+    Ll, row = L // R, L
+    nl = 2 * L * Ll
+    xs = x.reshape(nrhs, 2, L, row)
+
+    def rows(a, y0):
+        return a.reshape(2, L, row)[:, y0:y0 + Ll].reshape(-1)
+    for pieces in (P.P_EO | P.P_ZERO_E, P.P_OE | P.P_ZERO_O, P.P_HOPPING | P.P_ZERO):
+        want = qmg.DeviceArray.zeros(n * nrhs)
+        qmg.wilson_hops_direct(qmg.C64, d, g, want, D(x), pieces, w, scale, nrhs, n, 0b11)
+        want = want.to_host()
+        for r in range(R):
+            y0 = r * Ll
+            dl = qmg.make_desc(L, Ll, 2, None, None)
+            dx = D(np.concatenate([rows(x[k * n:(k + 1) * n], y0) for k in range(nrhs)]))
+            lo, hi = D(xs[:, :, (y0 - 1) % L].reshape(-1)), D(xs[:, :, (y0 + Ll) % L].reshape(-1))
+            for modes in ((0,), (1, 2)):
+                out = qmg.DeviceArray.zeros(nl * nrhs)
+                for rows_mode in modes:
+                    qmg.wilson_hops_direct(qmg.C64, dl, g, out, dx, pieces, w, scale, nrhs, nl, 0b11, gauge_Ly=L, y0=y0, halo_lo=lo, halo_hi=hi,
+                                           halo_stride=2 * row, rows=rows_mode)
+                got = out.to_host()
+                for k in range(nrhs):
+                    assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], y0)), (hex(pieces), R, r, k, modes)
