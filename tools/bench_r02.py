@@ -83,7 +83,7 @@ if want("fine"):
         ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C64, dW, g64, wl.lhs, wl.rhs, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
         row("k_wilson_direct<double> (kernel W) Wilson %d^2 fp64, from the links" % L, ms, 96 * vol, "96 B/site: links 32 + rhs 32 + lhs 32; bit-identical to the stored stencil")
         ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C64, dW, g64, wl.lhs, wl.rhs, qmg.P_EO | qmg.P_ZERO_E), reps=50, warm=10)
-        row("k_wilson_direct<double> D_eo %d^2 fp64" % L, ms, 80 * vol / 2, "one parity: links 32 + rhs 32 + lhs 16 per written site... counted as 80 B per written site")
+        row("k_wilson_direct<double> D_eo %d^2 fp64" % L, ms, 128 * vol / 2, "one parity, per written site: its four links 64 (every link of the lattice is read once) + rhs 32 + lhs 32")
         ms = timeit(lambda: qmg.wilson_apply_direct(qmg.C32, dW, g32, l32, r32, qmg.P_ALL | qmg.P_ZERO), reps=50, warm=10)
         row("k_wilson_direct<float> (kernel W) Wilson %d^2 fp32, from the links" % L, ms, 48 * vol, "48 B/site")
         g64.free(); g32.free()
