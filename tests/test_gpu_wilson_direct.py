@@ -133,6 +133,16 @@ def test_direct_apply_on_slabs_reads_the_global_links(R):
         got = out.to_host()
         for k in range(nrhs):
             assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], y0)), (R, r, k)
+        # one system: the two-rows-per-lane-group form of kernel W2 (row pairs starting at y = 0 with both halos for rows = 0, at the odd
+        # row y = 1 for the interior rows) must leave the same bytes
+        lo1, hi1 = D(xs[0, :, (y0 - 1) % L].reshape(-1)), D(xs[0, :, (y0 + Ll) % L].reshape(-1))
+        dx1 = D(rows(x[:n], y0))
+        for modes in ((0,), (1, 2)):
+            out1 = qmg.DeviceArray.zeros(nl)
+            for rows_mode in modes:
+                qmg.wilson_apply_direct(qmg.C64, dl, g, out1, dx1, P.P_ALL | P.P_ZERO, 1.0, gauge_Ly=L, y0=y0, halo_lo=lo1, halo_hi=hi1, halo_stride=2 * row,
+                                        rows=rows_mode)
+            assert np.array_equal(out1.to_host(), rows(want[:n], y0)), (R, r, modes)
 
 
 RBJ_SERVED = [P.P_EO | P.P_ZERO_E, P.P_OE | P.P_ZERO_O, P.P_EO, P.P_OE, P.P_HOPPING | P.P_ZERO, P.P_HOPPING]
