@@ -863,10 +863,16 @@ __device__ __forceinline__ void wave_lds_handoff() {
 // at 512^2, nc = 24, 16 rhs: the extra f64 adds and the third accumulator cost more than the saved MFMA -- and dropped.)
 // The f64 matrix pipe sustains 48 TFLOP/s on this part (tools/mfma_f64_rate.hip), which at nc = 24 is 2.7 ms of plain
 // MFMA work per 512^2 apply against 2.4 ms of HBM time -- the MFMA count, not the byte count, is what MODE 1 cuts.
+// MODE 2 (9-16 right-hand sides, fp64, VL): the REAL form of the product -- [yr; yi] = [[Mr, -Mi], [Mi, Mr]] [xr; xi], a (2 nc x 2 nc) real
+//         matrix against a (2 nc x 16) real right-hand side: ONE MFMA per 16 x 4 tile of it, each lane pulling the double it needs
+//         (re or im of M[r][c], sign by quadrant) straight out of the complex LDS tile.  The MFMA count is 2 nc/16 (rounded up) x nc/2
+//         per piece instead of MODE 0's 4 x ceil(nc/16) x ceil(nc/4): nc = 24: 36 instead of 48 (48 real rows fill three tiles exactly,
+//         24 complex rows waste a quarter of two), nc = 8: 4 instead of 8.  At 16 systems the kernel is MFMA-bound, so that is its time.
 template <int NC, int MODE, bool M32, bool V32, bool VL>
 __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
-  constexpr int RT = (NC + 15) / 16, KS = (NC + 3) / 4;
-  constexpr int NACC = 2;
+  static_assert(MODE != 2 || (VL && !M32 && NC % 2 == 0), "MODE 2: fp64, right-hand sides through the LDS slice");
+  constexpr int RT = (MODE == 2) ? (2 * NC + 15) / 16 : (NC + 15) / 16, KS = (MODE == 2) ? NC / 2 : (NC + 3) / 4;
+  constexpr int NACC = (MODE == 2) ? 1 : 2;
   // LDS row stride in tile elements: fp64 tile nc+1 complex (odd: conflict-free 16-B reads); fp32-stored matrices keep the
   // tile as raw complex<float> with stride nc+2 (even: 16-B aligned pair stores) -- half the LDS and half the staging
   // registers, widened to fp64 only as an MFMA operand
@@ -1009,6 +1015,37 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       wave_lds_handoff();
     };
     auto mac_piece = [&](int set) {
+      if constexpr (MODE == 2) {
+        // operands of k-step q+1 are read from LDS while the MFMAs of k-step q issue; the scheduling barrier keeps the compiler from
+        // hoisting ALL 48 operand reads of the piece in front of the first MFMA (238 VGPRs, one wavefront per SIMD)
+        double av[2][RT], bv[2];
+        auto fetch = [&](int q, int slot) {
+          const int K = 4 * q + lq;                      // 0 .. 2 nc - 1: the first nc multiply Re x, the rest Im x
+          const bool khi = K >= NC;
+          const int kc = khi ? K - NC : K;
+          bv[slot] = reinterpret_cast<const double*>(xlds + kcol * XS + kc)[khi ? 1 : 0];
+#pragma unroll
+          for (int t = 0; t < RT; t++) {
+            const int R = 16 * t + lr;                   // 0 .. 2 nc - 1: the first nc are Re y, the rest Im y
+            const bool rhi = R >= NC;
+            const int rr = rhi ? R - NC : R;
+            double v = 0.0;
+            if ((2 * NC) % 16 == 0 || R < 2 * NC) {
+              v = reinterpret_cast<const double*>(mlds + rr * RS + kc)[rhi != khi ? 1 : 0];   // diagonal quadrants: Re M; off-diagonal: Im M ...
+              if (!rhi && khi) v = -v;                                                        // ... with a minus in the upper right one
+            }
+            av[slot][t] = v;
+          }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+          if (q + 1 < KS) fetch(q + 1, (q + 1) & 1);
+#pragma unroll
+          for (int t = 0; t < RT; t++) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q & 1][t], bv[q & 1], acc[0][t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < KS; q++) {
         cplx Af[RT];
@@ -1064,6 +1101,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
           }
         }
       }
+      }
     };
 
     // software pipeline over the five piece slots (activity is uniform over the block).  Slot pc+1 is prefetched while
@@ -1086,19 +1124,30 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       // results into the vector slice [k][r] (the last piece's fragment reads are done), then lane-linear over [k][r]:
       // coalesced own-site read for the shift term, coalesced read-modify-write of the output
       wave_lds_handoff();
+      if constexpr (MODE == 2) {   // real row R of system lr: Re (R < nc) or Im of output row R mod nc
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int R = 16 * t + 4 * i + lq;
+            if ((2 * NC) % 16 == 0 || R < 2 * NC) reinterpret_cast<double*>(xlds + kcol * XS + (R >= NC ? R - NC : R))[R >= NC ? 1 : 0] = acc[0][t][i];
+          }
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < RT; t++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int r = F32M ? 16 * t + 4 * lq + i : 16 * t + 4 * i + lq;   // C/D row of accumulator register i: the f32 instruction puts rows 4 lq .. 4 lq + 3 in a lane, the f64 one rows lq, lq + 4, ...
           cplx v;
-          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[1][t][i]);
+          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[NACC - 1][t][i]);
           else {   // partner lane (lr ^ 8) holds the other half of the packed columns
-            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[1][t][i], 8);
-            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[1][t][i]);
+            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[NACC - 1][t][i], 8);
+            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[NACC - 1][t][i]);
           }
           if (r < NC && (MODE != 1 || lr < 8)) xlds[kcol * XS + r] = v;
         }
+      }
       }
       wave_lds_handoff();
 #pragma unroll
@@ -1125,10 +1174,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         for (int i = 0; i < 4; i++) {
           const int r = F32M ? 16 * t + 4 * lq + i : 16 * t + 4 * i + lq;   // C/D row of accumulator register i: the f32 instruction puts rows 4 lq .. 4 lq + 3 in a lane, the f64 one rows lq, lq + 4, ...
           cplx v;
-          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[1][t][i]);
+          if (MODE == 0) v = cmake((double)acc[0][t][i], (double)acc[NACC - 1][t][i]);
           else {   // partner lane (lr ^ 8) holds the other half of the packed columns
-            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[1][t][i], 8);
-            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[1][t][i]);
+            const double pp = (double)__shfl_xor(acc[0][t][i], 8), qp = (double)__shfl_xor(acc[NACC - 1][t][i], 8);
+            v = cmake((double)acc[0][t][i] - qp, pp + (double)acc[NACC - 1][t][i]);
           }
           if (r < NC && kval && (MODE != 1 || lr < 8)) {
             const long o = koff + site * NC + r;
@@ -1454,7 +1503,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       b.rhs = (const char*)a.rhs + (size_t)k0 * a.vec_stride * (vec32 ? 8 : 16);
       const int nk = (a.nrhs - k0 < 16) ? a.nrhs - k0 : 16;
       size_t smem = a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * nc * (nc + 2) : sizeof(cplx) * (size_t)(BLOCK / WAVE) * nc * (nc + 1);
-      const int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
+      int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
+      // 9-16 systems in fp64: the real-form tiles where they save MFMAs (nc = 24: 36 instead of 48 per piece; nc = 8: 4 instead of 8)
+      if (mode == 0 && g_stencil_mfma == 1 && g_mfma_vl && !a.mat32 && !a.vec32 && (nc == 24 || nc == 8)) mode = 2;
       if (g_mfma_vl && !(mode == 0 && a.mat32)) smem += sizeof(cplx) * (size_t)(BLOCK / WAVE) * (mode == 1 ? 8 : 16) * (nc + 1);   // the wavefronts' vector slices
 #define QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, VL)                                                              \
       {                                                                                                         \
@@ -1466,7 +1517,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #define QMG_MFMA_LAUNCH2(NC, MODE)                                                                              \
       { if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
-      if (mode == 0) QMG_MFMA_LAUNCH2(NC, 0) else QMG_MFMA_LAUNCH2(NC, 1)
+      if (mode == 2) QMG_MFMA_LAUNCH0(NC, 2, false, false, true) else if (mode == 0) QMG_MFMA_LAUNCH2(NC, 0) else QMG_MFMA_LAUNCH2(NC, 1)
       switch (nc) {
         case 8: QMG_MFMA_LAUNCH(8) break;
         case 12: QMG_MFMA_LAUNCH(12) break;

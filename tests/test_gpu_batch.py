@@ -107,7 +107,8 @@ def test_batch_multidot_and_multi_caxpy(nj):
     assert cs.rel_l2(out, want) < TOL
 
 
-@pytest.mark.parametrize("nc,nrhs,mask", [(2, 4, 0b1011), (1, 3, 0b101), (8, 6, 0b110101), (24, 16, 0xFFFF), (24, 12, 0b101010111011), (3, 4, 0b0110), (16, 2, 0b10)])
+@pytest.mark.parametrize("nc,nrhs,mask", [(2, 4, 0b1011), (1, 3, 0b101), (8, 6, 0b110101), (24, 16, 0xFFFF), (24, 12, 0b101010111011), (3, 4, 0b0110), (16, 2, 0b10),
+                                          (8, 16, 0xFFFF), (8, 11, 0x7FF), (24, 9, 0x1FF), (12, 16, 0xFFFF), (32, 10, 0x3FF)])
 def test_stencil_apply_batch_masked(nc, nrhs, mask):
     Lx, Ly = 12, 6
     vol = Lx * Ly
