@@ -417,7 +417,7 @@ def wilson_from_links(qmg, L, fixture, steps, warmup, barrier):
                      "speedup_over_the_stored_stencil_bytes": (384 if name == "fp64" else 192) / bytes_site,
                      "roofline": {"bound": "hbm", "achieved": bytes_site * vol / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": bytes_site * vol / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                  "kernel": "k_wilson_direct<%s,1,true,false>" % ("double" if name == "fp64" else "float"),
+                                  "kernel": "k_wilson_pair2<%s,true> (kernel W2, both parities x two rows per lane group)" % ("double" if name == "fp64" else "float"),
                                   "algorithmic_bytes_per_launch": bytes_site * vol, "avg_launch_ms": kern_ms,
                                   "note": "%d B/site: links %d (each link serves the two sites it joins) + rhs + lhs" % (bytes_site, bytes_site // 3)}}
         rhs.free()
