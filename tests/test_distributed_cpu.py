@@ -26,10 +26,18 @@ def test_shard_rhs_partitions():
         sharding.shard_rhs(4, 2, 2)
 
 
+def _free_port():
+    """a port nobody listens on right now (fixed ports can collide with a run that has not released them yet)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_two_rank_gloo_worker():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tests", "dist_worker.py")]
+           "--master-port", _free_port(), os.path.join(ROOT, "tests", "dist_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
@@ -41,7 +49,7 @@ def test_two_rank_slab_solve():
     oracle (tests/slab_worker.py).  The HIP side of the same path is tests/test_gpu_slab.py."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "tests", "slab_worker.py")]
+           "--master-port", _free_port(), os.path.join(ROOT, "tests", "slab_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "slab worker ok" in out.stdout
