@@ -64,7 +64,7 @@ def test_c3_wilson_kcycle_2048_three_levels_nc24(golden_dir):
 
 def test_c4_staggered_4096_eight_rhs_norms_and_allreduce(golden_dir, monkeypatch):
     """configs[3], one GPU's share: staggered Dslash at 4096^2 for 8 right-hand sides sharing one read of the hopping
-    matrices, the per-RHS norm2sq, and ONE qmg_allreduce_sum_f64 of the norm buffer through a (forced) one-rank RCCL
+    matrices, the per-RHS norm2sq (separately, and fused into the apply as bench.py runs it), and ONE qmg_allreduce_sum_f64 of the norm buffer through a (forced) one-rank RCCL
     communicator obtained by qmg_comm_init_env.  Gate: periodic image of the oracle's 64^2 result on the LAST right-hand
     side (1e-13); every norm against numpy (1e-12); the all-reduce leaves the one rank's values unchanged."""
     import bench
@@ -94,6 +94,18 @@ def test_c4_staggered_4096_eight_rhs_norms_and_allreduce(golden_dir, monkeypatch
     assert np.linalg.norm(got[(nrhs - 1) * vol:] - want) / np.linalg.norm(want) < 1e-13
     ref = np.array([np.vdot(got[k * vol:(k + 1) * vol], got[k * vol:(k + 1) * vol]).real for k in range(nrhs)])
     assert np.allclose(norms.to_host(), ref, rtol=1e-12)
+    # the step as bench.py runs it: the apply leaves the norms from the same pass (qmg_stencil_apply_norm2) -- same bytes in lhs,
+    # norms to rounding of the separate reductions, bit-reproducible from launch to launch
+    lhs2, fused = qmg.DeviceArray(nrhs * vol), qmg.DeviceArray(nrhs, np.float64)
+    qmg.stencil_apply_norm2(desc, lhs2, rhs, qmg.P_ALL | qmg.P_ZERO, nrhs, vol, norms_dev=fused.ptr)
+    qmg.sync()
+    assert np.array_equal(lhs2.to_host(), got)
+    first = fused.to_host()
+    assert np.allclose(first, ref, rtol=1e-13)
+    qmg.stencil_apply_norm2(desc, lhs2, rhs, qmg.P_ALL | qmg.P_ZERO, nrhs, vol, norms_dev=fused.ptr)
+    qmg.sync()
+    assert np.array_equal(fused.to_host(), first)
+    lhs2.free(); fused.free()
     monkeypatch.setenv("QMG_COMM_FORCE_RCCL", "1")
     qmg.comm_init_env(1, 0)
     assert qmg.comm_all_ok(True)
