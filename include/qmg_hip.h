@@ -122,7 +122,7 @@ int qmg_cshift(void* lhs, const void* rhs, int cdir, int eo, int dof, int Lx, in
 int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                       int nrhs, size_t vec_stride, void* stream);
 /* The apply with the norms of its results from the same pass: lhs_k (+)= pieces(M) rhs_k and norms[k] = |lhs_k|^2 (the
- * apply followed by norm2sq of vector_reductions.h:97-120 without re-reading the vector: 40 instead of 56 B/site/rhs for
+ * apply followed by quantum-linalg's norm2sq -- call sites stateful_multigrid.h:880,884 -- without re-reading the vector: 40 instead of 56 B/site/rhs for
  * the staggered operator).  fp64, nc = 1 or 2, pieces touching BOTH parities, lhs != rhs, nrhs <= 16; anything else, or a
  * call while distributed reductions are on, is QMG_ERR_UNSUPPORTED.  lhs receives the bytes qmg_stencil_apply writes; the
  * norms are summed in a fixed order (run-to-run reproducible), not in qmg_norm2sq's order (they agree to rounding).
