@@ -525,25 +525,32 @@ def slab_kcycle_c5(world, rank):
     try:
         # one child: the fp64 solve, then (`nrhs=1 f32`) the same system again with the K-cycle preconditioner in complex<float>
         p = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur", "nrhs=1", "f32"], cwd=drivers, env=env, capture_output=True, text=True, timeout=180)
-    except subprocess.TimeoutExpired:
-        return {"error": "n22_wilson_kcycle_adaptive (slab mode) timed out after 180 s on rank %d" % rank}
+        stdout, stderr, rc, timed_out = p.stdout, p.stderr, p.returncode, False
+    except subprocess.TimeoutExpired as e:   # keep what the fp64 part printed before the fp32 part ran out of time
+        dec = lambda b: b.decode(errors="replace") if isinstance(b, bytes) else (b or "")
+        stdout, stderr, rc, timed_out = dec(e.stdout), dec(e.stderr), 0, True
     if rank != 0:
-        return {"rank": rank, "rc": p.returncode} if p.returncode == 0 else {"error": "rc %d on rank %d" % (p.returncode, rank)}
-    m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
-    c = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
-    sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", p.stdout)
-    t = re.search(r"\[QMG-TIMING\]: setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
-    if not (m and c and sl and t) or p.returncode != 0:
-        return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
+        if timed_out:
+            return {"error": "n22_wilson_kcycle_adaptive (slab mode) timed out after 180 s on rank %d" % rank}
+        return {"rank": rank, "rc": rc} if rc == 0 else {"error": "rc %d on rank %d" % (rc, rank)}
+    m = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", stdout)
+    c = re.search(r"Check tolerance ([\d.e+-]+)", stdout)
+    sl = re.search(r"\[QMG-SLAB\]: world (\d+) ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", stdout)
+    t = re.search(r"\[QMG-TIMING\]: setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", stdout)
+    if not (m and c and sl and t) or rc != 0:
+        return {"error": "timed out after 180 s" if timed_out else "rc %d" % rc, "tail": (stdout + stderr)[-600:]}
     out = {"workload": "adaptive Wilson K-cycle (n22 parameters, 1 adaptive pass), 4096x4096, 4 levels, coarse nc=8, red-black on every level, fp64, ONE lattice cut into %d y-slab(s)" % world,
            "scaling": "strong", "world": int(sl.group(1)), "converged": m.group(1) == "converged", "outer_iterations": int(m.group(2)),
            "true_residual_original_system": float(c.group(1)), "x_norm2": float(sl.group(3)), "setup_s": float(t.group(1)), "solve_s": float(t.group(2)),
            "outer_iterations_per_s": float(t.group(3))}
-    f = re.search(r"\[QMG-MRHS\]: rhs 0 converged in (\d+) iterations ; alleged tolerance ([\d.e+-]+) ; check tolerance ([\d.e+-]+)", p.stdout)
-    ft = re.search(r"batched solve of 1 systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+)", p.stdout)
+    f = re.search(r"\[QMG-MRHS\]: rhs 0 converged in (\d+) iterations ; alleged tolerance ([\d.e+-]+) ; check tolerance ([\d.e+-]+)", stdout)
+    ft = re.search(r"batched solve of 1 systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+)", stdout)
     if f and ft:   # BASELINE configs[4] as written (fp32): the K-cycle in complex<float> inside the fp64 outer solve, same slabs
         out["fp32_kcycle"] = {"outer_iterations": int(f.group(1)), "true_residual_original_system": float(f.group(3)), "solve_s": float(ft.group(1)),
                               "outer_iterations_per_s": float(ft.group(2))}
+    elif timed_out:
+        out["fp32_kcycle"] = {"error": "the fp32 part of the child did not finish within the child's 180 s"}
+        out["error_fp32"] = True
     return out
 
 
