@@ -366,7 +366,7 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
   const double true_res = sqrt(diffnorm2sq(b, Ax, n0)) / bnorm;
   cout << "Check tolerance " << true_res << "\n";
   if (slab_mode) { const double xn = norm2sq(x_rec, n0); cout << setprecision(15) << "[QMG-SLAB]: world " << proc_world << " ; |b| " << bnorm << " ; |x|^2 " << xn << "\n" << setprecision(20); }
-  cout << setprecision(6) << "[QMG-TIMING]: setup " << setup_s << " s ; solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
+  cout << setprecision(6) << "[QMG-TIMING]: setup " << setup_s << " s ; solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n" << std::flush;   // (a parent that times the batched part out still reads this)
   mg_object->check_in(x_rec, 0); mg_object->check_in(b_prep, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);
 
   bool ok_ = invif.success && true_res < 20 * tol;
