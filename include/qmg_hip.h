@@ -336,6 +336,10 @@ int qmg_coarse_build_slab(void* cclover, void* chopping, const qmg_stencil_desc*
 int qmg_gaussian_slab(void* x, int Lx, int Ly_global, int y0, int Ly_local, int nc, unsigned long long seed, void* stream);
 /* right-block-Jacobi hopping on a slab: after qmg_build_rbjacobi(cinv, rb_clover, NULL, d) and a halo exchange of cinv (nc^2 components) */
 int qmg_rb_hopping_slab(void* rb_hopping, const qmg_stencil_desc* d, const void* cinv, const void* cinv_halo_lo, const void* cinv_halo_hi, void* stream);
+/* build_dagger_stencil (stencil_2d.h:1080-1139) on a y-slab.  ym_halo_hi: the `hi` buffer of qmg_halo_exchange applied to the -y hopping
+ * field (hopping + 3 size_cm, nc^2 components per site); yp_halo_lo: the `lo` buffer of the exchange of the +y field (hopping + size_cm). */
+int qmg_build_dagger_slab(void* dclover, void* dhopping, const void* clover, const void* hopping, int Lx, int Ly, int nc,
+                          const void* ym_halo_hi, const void* yp_halo_lo, void* stream);
 /* Test transport: `world` host threads of one process act as ranks on one GPU (device copies + host sums behind thread barriers),
  * because one-GPU boxes cannot run two RCCL ranks.  Everything above the transport is the code the RCCL path runs. */
 int qmg_comm_emulate_begin(int world);

@@ -134,8 +134,10 @@ __global__ __launch_bounds__(BLOCK) void k_nc1_fill(cplx* __restrict__ clover, c
 
 // ---- batched conjugate transpose (cMATcopy_conjtrans_square), optionally gathered from a neighbour ----
 // out[site][r][c] = conj(in[src(site)][c][r]);  cdir == 0: src = site.
+// (y-slab: the source matrices of rows -1 / Ly come from `halo` = the neighbouring rank's boundary row of the SAME field,
+//  [parity][hr][nc^2], filled by qmg_halo_exchange of that field with nc^2 components per site)
 __global__ __launch_bounds__(BLOCK) void k_conjtrans(cplx* __restrict__ out, const cplx* __restrict__ in, long nsite,
-                                                     int nc, int cdir, int hr, int Ly) {
+                                                     int nc, int cdir, int hr, int Ly, const cplx* __restrict__ halo = nullptr) {
   const long nc2 = (long)nc * nc;
   const long total = nsite * nc2;
   const long half_vol = (long)hr * Ly;
@@ -144,13 +146,18 @@ __global__ __launch_bounds__(BLOCK) void k_conjtrans(cplx* __restrict__ out, con
     const int e = (int)(t - site * nc2);
     const int r = e / nc, c = e - r * nc;
     long src = site;
+    const cplx* from = in;
     if (cdir) {
       const int p = (int)(site / half_vol);
       const long wi = site - (long)p * half_vol;
       const int y = (int)(wi / hr), j = (int)(wi - (long)y * hr);
       src = neighbour_site(cdir, p, y, j, hr, Ly, half_vol);
+      if (halo && ((cdir == QMG_CSHIFT_FROM_YP1 && y + 1 == Ly) || (cdir == QMG_CSHIFT_FROM_YM1 && y == 0))) {
+        from = halo;
+        src = (long)(1 - p) * hr + j;               // the opposite-parity site of the neighbouring rank's boundary row
+      }
     }
-    out[t] = cconj(in[src * nc2 + (long)c * nc + r]);
+    out[t] = cconj(from[src * nc2 + (long)c * nc + r]);
   }
 }
 
@@ -379,6 +386,32 @@ int qmg_build_dagger(void* dclover, void* dhopping, const void* clover, const vo
     for (int dir = 0; dir < 4; dir++) {
       k_conjtrans<<<grid_1d((size_t)cm), BLOCK, 0, st>>>((cplx*)dhopping + dir * cm, (const cplx*)hopping + src_dir[dir] * cm,
                                                          vol, nc, cdir[dir], Lx / 2, Ly);
+      QMG_LAUNCH_CHECK();
+    }
+  }
+  return QMG_SUCCESS;
+}
+
+// build_dagger_stencil on a y-slab: dagger[+y](x) at the slab's last row needs hopping[-y] of the next rank's first row, dagger[-y](x)
+// at its first row hopping[+y] of the previous rank's last row.  ym_halo_hi = the `hi` buffer of qmg_halo_exchange applied to the -y
+// field (hopping + 3 size_cm) with nc^2 components per site, yp_halo_lo = the `lo` buffer of the exchange of the +y field
+// (hopping + size_cm).  Everything else is site-local or inside a row.
+int qmg_build_dagger_slab(void* dclover, void* dhopping, const void* clover, const void* hopping, int Lx, int Ly, int nc,
+                          const void* ym_halo_hi, const void* yp_halo_lo, void* stream) {
+  if (!valid_lattice(Lx, Ly) || nc < 1 || (hopping && dhopping && (!ym_halo_hi || !yp_halo_lo))) return QMG_ERR_INVALID;
+  const long vol = (long)Lx * Ly, cm = vol * nc * nc;
+  hipStream_t st = as_stream(stream);
+  if (clover && dclover) {
+    k_conjtrans<<<grid_1d((size_t)cm), BLOCK, 0, st>>>((cplx*)dclover, (const cplx*)clover, vol, nc, 0, Lx / 2, Ly);
+    QMG_LAUNCH_CHECK();
+  }
+  if (hopping && dhopping) {
+    const int src_dir[4] = {2, 3, 0, 1};
+    const int cdir[4] = {QMG_CSHIFT_FROM_XP1, QMG_CSHIFT_FROM_YP1, QMG_CSHIFT_FROM_XM1, QMG_CSHIFT_FROM_YM1};
+    const void* halo[4] = {nullptr, ym_halo_hi, nullptr, yp_halo_lo};
+    for (int dir = 0; dir < 4; dir++) {
+      k_conjtrans<<<grid_1d((size_t)cm), BLOCK, 0, st>>>((cplx*)dhopping + dir * cm, (const cplx*)hopping + src_dir[dir] * cm, vol, nc, cdir[dir], Lx / 2, Ly,
+                                                         (const cplx*)halo[dir]);
       QMG_LAUNCH_CHECK();
     }
   }

@@ -34,9 +34,39 @@ static int run(int rank, int world, int device, int argc, char** argv) {
   const long n = lats[0]->get_size_cv_l();
   int nrhs = 0;
   bool f32 = false;
+  bool adjoint = false;
   for (int i = 8; i < argc; i++) {
     if (std::string(argv[i]).rfind("nrhs=", 0) == 0) nrhs = atoi(argv[i] + 5);
     if (std::string(argv[i]) == "f32") f32 = true;
+    if (std::string(argv[i]) == "adjoint") adjoint = true;
+  }
+  if (adjoint) {
+    // `adjoint`: build_dagger_stencil on every level's slab (the boundary rows' +-y hops come from the neighbouring ranks: one exchange of
+    // the -y and one of the +y hopping field) and check <u, M v> = <M^dag u, v> with the distributed reductions -- a dagger stencil whose
+    // boundary rows were wired to the wrong rank breaks the identity at O(1)
+    int good = 1;
+    for (int level = 0; level < mg_object->get_num_levels(); level++) {
+      Stencil2D* st = mg_object->get_stencil(level);
+      Lattice2D* lat = lats[level];
+      const long nl = lat->get_size_cv_l();
+      complex<double>*u = mg_object->check_out(level), *v = mg_object->check_out(level), *w = mg_object->check_out(level);
+      gaussian_lattice(u, lat->get_dim_mu(0), lat->get_dim_mu(1), lat->get_nc(), seed++);
+      gaussian_lattice(v, lat->get_dim_mu(0), lat->get_dim_mu(1), lat->get_nc(), seed++);
+      st->build_dagger_stencil();
+      zero_vector(w, nl); st->apply_M(w, v);
+      const complex<double> d1 = dot(u, w, nl);
+      zero_vector(w, nl); st->apply_M_dagger(w, u);
+      const complex<double> d2 = dot(w, v, nl);
+      const double rel = std::abs(d1 - d2) / std::abs(d1);
+      if (!(rel < 1e-12)) good = 0;
+      if (root) cout << setprecision(15) << "[QMG-SLAB]: level " << level << " <u, M v> = " << d1 << " ; <M^dag u, v> = " << d2 << " ; rel diff " << rel << (rel < 1e-12 ? " (ok)" : " (MISMATCH)") << "\n";
+      mg_object->check_in(w, level); mg_object->check_in(v, level); mg_object->check_in(u, level);
+    }
+    qmg_comm_all_ok(good, &all);
+    s.destroy();
+    qmg::slab_end();
+    qmg_comm_finalize();
+    return all ? 0 : 1;
   }
   if (nrhs > 0) {   // the lock-step batch engine on slabs: one halo exchange per batch apply, per-system reductions summed over the ranks
     const bool ok_b = mrhs_solve_and_report(mg_object, lats[0], nrhs, seed, s.tol, s.max_iter, s.restart_freq, true, 0, s.setup_s, 0, 0, QMG_MATVEC_ORIGINAL, f32);

@@ -596,12 +596,30 @@ struct Stencil2D {
   }
 
   // ================= dagger stencil (:1080-1446) =================
+  // dagger of (cl, ho) into (dcl, dho) (stencil_2d.h:1080-1139).  On a y-slab the +-y hops of the boundary rows are the conjugate
+  // transposes of matrices the neighbouring ranks hold: one halo exchange of the -y field and one of the +y field (nc^2 components per site)
+  void build_dagger_arrays(complex<double>* dcl, complex<double>* dho, const complex<double>* cl, const complex<double>* ho) {
+    const int Lx = lat->get_dim_mu(0), Ly = lat->get_dim_mu(1), nc = lat->get_nc();
+    if (!(qmg::slab().on && ho && dho)) {
+      qmg::ok(qmg_build_dagger(dcl, dho, cl, ho, Lx, Ly, nc, qmg::current_stream()), "qmg_build_dagger");
+      return;
+    }
+    const size_t hs = (size_t)Lx * nc * nc, cm = lat->get_size_cm_l();
+    complex<double>* buf = allocate_vector<complex<double>>(4 * hs);   // lo / hi of the -y field, lo / hi of the +y field
+    if (!buf) { std::cout << "[QMG-ERROR]: no memory for the halo rows of the dagger build\n"; return; }
+    void* st = qmg::current_stream();
+    bool good = qmg::ok(qmg_halo_exchange(QMG_C64, ho + 3 * cm, Lx, Ly, nc * nc, buf, buf + hs, 1, 0, hs, st), "qmg_halo_exchange") &&
+                qmg::ok(qmg_halo_exchange(QMG_C64, ho + cm, Lx, Ly, nc * nc, buf + 2 * hs, buf + 3 * hs, 1, 0, hs, st), "qmg_halo_exchange");
+    if (good) qmg::ok(qmg_build_dagger_slab(dcl, dho, cl, ho, Lx, Ly, nc, buf + hs, buf + 2 * hs, st), "qmg_build_dagger_slab");
+    qmg::ok(qmg_stream_sync(st), "qmg_stream_sync");
+    deallocate_vector(&buf);
+  }
+
   void build_dagger_stencil() {
     if (built_dagger) { std::cout << "[QMG-WARNING]: Tried to call build_dagger_stencil, but it's already been called once.\n"; return; }
     if (clover != 0) dagger_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
     if (hopping != 0) dagger_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
-    qmg::ok(qmg_build_dagger(dagger_clover, dagger_hopping, clover, hopping, lat->get_dim_mu(0), lat->get_dim_mu(1), lat->get_nc(), qmg::current_stream()),
-            "qmg_build_dagger");
+    build_dagger_arrays(dagger_clover, dagger_hopping, clover, hopping);
     if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
     if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
     built_dagger = true;
@@ -809,7 +827,7 @@ struct Stencil2D {
     const int Lx = lat->get_dim_mu(0), Ly = lat->get_dim_mu(1), nc = lat->get_nc();
     if (rbjacobi_clover != 0) rbj_dagger_clover = allocate_vector<complex<double>>(lat->get_size_cm_l());
     if (rbjacobi_hopping != 0) rbj_dagger_hopping = allocate_vector<complex<double>>(lat->get_size_hopping_l());
-    qmg::ok(qmg_build_dagger(rbj_dagger_clover, rbj_dagger_hopping, rbjacobi_clover, rbjacobi_hopping, Lx, Ly, nc, qmg::current_stream()), "qmg_build_dagger");
+    build_dagger_arrays(rbj_dagger_clover, rbj_dagger_hopping, rbjacobi_clover, rbjacobi_hopping);
     if (rbjacobi_cinv != 0) {
       rbj_dagger_cinv = allocate_vector<complex<double>>(lat->get_size_cm_l());
       qmg::ok(qmg_cmat_conjtrans(rbj_dagger_cinv, rbjacobi_cinv, (size_t)lat->get_volume(), nc, qmg::current_stream()), "qmg_cmat_conjtrans");

@@ -508,3 +508,53 @@ def test_coarse_batches_on_slabs_through_the_mfma_kernel(nc, nrhs, mask, f32):
         got = out.to_host()
         for k in range(nrhs):
             assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], Ly, row, y0, Ll)), (nc, r, k)
+
+
+@pytest.mark.parametrize("R,nc", [(2, 2), (4, 3), (2, 8)])
+def test_dagger_build_on_slabs_matches_the_rows_of_the_single_domain_build(R, nc):
+    """build_dagger_stencil (stencil_2d.h:1080-1139) on y-slabs: dagger[+y] of a slab's last row is the conjugate transpose of the NEXT rank's
+    first-row hopping[-y], dagger[-y] of its first row that of the PREVIOUS rank's last-row hopping[+y] (qmg_build_dagger_slab with the two halo
+    rows qmg_halo_exchange delivers).  Bit for bit the rows of the single-domain build."""
+    Lx = Ly = 16
+    hr, nc2, vol = Lx // 2, nc * nc, Lx * Ly
+    clover = cs.gaussian_cvec(vol * nc2, 31)
+    hopping = cs.gaussian_cvec(4 * vol * nc2, 32)
+    dcl, dho = qmg.DeviceArray(vol * nc2), qmg.DeviceArray(4 * vol * nc2)
+    qmg.build_dagger(dcl, dho, D(clover), D(hopping), Lx, Ly, nc)
+    want_cl = dcl.to_host().reshape(2, Ly, hr, nc2)
+    want_ho = dho.to_host().reshape(4, 2, Ly, hr, nc2)
+    cl_g = clover.reshape(2, Ly, hr, nc2)
+    ho_g = hopping.reshape(4, 2, Ly, hr, nc2)
+    Ll = Ly // R
+    for r in range(R):
+        y0 = r * Ll
+        cl_l = np.ascontiguousarray(cl_g[:, y0:y0 + Ll]).reshape(-1)
+        ho_l = np.ascontiguousarray(ho_g[:, :, y0:y0 + Ll]).reshape(-1)
+        ym_hi = np.ascontiguousarray(ho_g[3, :, (y0 + Ll) % Ly]).reshape(-1)     # [parity][hr][nc^2]: the next rank's first row of the -y field
+        yp_lo = np.ascontiguousarray(ho_g[1, :, (y0 - 1) % Ly]).reshape(-1)      # the previous rank's last row of the +y field
+        ocl, oho = qmg.DeviceArray(Lx * Ll * nc2), qmg.DeviceArray(4 * Lx * Ll * nc2)
+        qmg.build_dagger_slab(ocl, oho, D(cl_l), D(ho_l), Lx, Ll, nc, D(ym_hi), D(yp_lo))
+        assert np.array_equal(ocl.to_host().reshape(2, Ll, hr, nc2), want_cl[:, y0:y0 + Ll]), (R, r)
+        assert np.array_equal(oho.to_host().reshape(4, 2, Ll, hr, nc2), want_ho[:, :, y0:y0 + Ll]), (R, r)
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_dagger_stencils_on_slabs_satisfy_the_adjoint_identity(R):
+    """Facade slab mode: build_dagger_stencil on every level of an n13 hierarchy (Wilson fine level, Galerkin coarse levels, nc = 8) with the
+    boundary rows' +-y hops taken from the neighbouring ranks, then <u, M v> = <M^dag u, v> with the reductions summed over the ranks
+    (drivers/n13_wilson_kcycle_slab.cpp ... adjoint).  Wiring the boundary rows to the slab's own opposite edge (what the single-domain
+    build would do on a slab) breaks the identity at O(1)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    args = ["128", "-0.05", "6.0", "2", "8", gauge, "64", "adjoint"]
+    env = dict(os.environ, QMG_QUIET="1")
+    env.update({"QMG_COMM_EMULATE": str(R)} if R > 1 else {"RANK": "0", "WORLD_SIZE": "1"})
+    out = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    rows = re.findall(r"\[QMG-SLAB\]: level (\d) .* rel diff ([-\d.e+]+) \((ok|MISMATCH)\)", out.stdout)
+    assert len(rows) == 3 and all(r[2] == "ok" and float(r[1]) < 1e-12 for r in rows), out.stdout[-2000:]
