@@ -16,6 +16,11 @@ inline void cshift(complex<double>* lhs, complex<double>* rhs, int cdir, int eo,
     if (eo & 2) std::cout << "[ERROR-QMG]: cshift_from_odd does not support distance two stencils yet.\n";
     return;
   }
+  if (qmg::slab().on && qmg::slab().world > 1 && (cdir == QMG_CSHIFT_FROM_YP1 || cdir == QMG_CSHIFT_FROM_YM1)) {
+    // a y-shift of a slab needs the neighbouring rank's row (the stencil applies take it from qmg_halo_exchange); this host-side utility does not
+    std::cout << "[QMG-ERROR]: cshift in the y direction is not decomposed into y-slabs.\n";
+    return;
+  }
   qmg::ok(qmg_cshift(lhs, rhs, cdir, eo, dof_per_site, lat->get_dim_mu(0), lat->get_dim_mu(1), qmg::current_stream()), "qmg_cshift");
 }
 inline void cshift_from_even(complex<double>* lhs, complex<double>* rhs, int cdir, int dof, Lattice2D* lat) { cshift(lhs, rhs, cdir, 1, dof, lat); }
