@@ -340,6 +340,10 @@ int qmg_rb_hopping_slab(void* rb_hopping, const qmg_stencil_desc* d, const void*
  * field (hopping + 3 size_cm, nc^2 components per site); yp_halo_lo: the `lo` buffer of the exchange of the +y field (hopping + size_cm). */
 int qmg_build_dagger_slab(void* dclover, void* dhopping, const void* clover, const void* hopping, int Lx, int Ly, int nc,
                           const void* ym_halo_hi, const void* yp_halo_lo, void* stream);
+/* The nc = 1 operator fills on a y-slab (rows y0 .. y0 + Ly_local - 1, y0 even) from the GLOBAL gauge field, as qmg_wilson_fill_slab:
+ * Staggered2D (staggered.h:50-72) and GaugedLaplace2D (gaugedlaplace.h:45-68). */
+int qmg_staggered_fill_slab(void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, void* stream);
+int qmg_laplace_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, void* stream);
 /* Test transport: `world` host threads of one process act as ranks on one GPU (device copies + host sums behind thread barriers),
  * because one-GPU boxes cannot run two RCCL ranks.  Everything above the transport is the code the RCCL path runs. */
 int qmg_comm_emulate_begin(int world);

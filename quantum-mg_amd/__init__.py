@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_norm2",
-    "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
+    "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_staggered_fill_slab", "qmg_laplace_fill_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -216,6 +216,14 @@ def laplace_fill(clover, hopping, gauge, Lx, Ly, stream=None):
 
 def build_dagger(dclover, dhopping, clover, hopping, Lx, Ly, nc, stream=None):
     check(lib().qmg_build_dagger(_vp(dclover), _vp(dhopping), _vp(clover), _vp(hopping), Lx, Ly, nc, C.c_void_p(stream)), "qmg_build_dagger")
+
+
+def staggered_fill_slab(hopping, gauge_global, Lx, Ly_global, y0, Ly_local, stream=None):
+    check(lib().qmg_staggered_fill_slab(_vp(hopping), _vp(gauge_global), Lx, Ly_global, y0, Ly_local, C.c_void_p(stream)), "qmg_staggered_fill_slab")
+
+
+def laplace_fill_slab(clover, hopping, gauge_global, Lx, Ly_global, y0, Ly_local, stream=None):
+    check(lib().qmg_laplace_fill_slab(_vp(clover), _vp(hopping), _vp(gauge_global), Lx, Ly_global, y0, Ly_local, C.c_void_p(stream)), "qmg_laplace_fill_slab")
 
 
 def build_dagger_slab(dclover, dhopping, clover, hopping, Lx, Ly, nc, ym_halo_hi, yp_halo_lo, stream=None):

@@ -106,16 +106,21 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_fill_slab(cplx* __restrict__ c
 
 // ---- Staggered2D (staggered.h:50-72; eta_y = 1 - 2 (x % 2), :253-259) and GaugedLaplace2D (gaugedlaplace.h:45-68) ----
 // mode 0: staggered (hopping only) ; mode 1: gauged Laplace (clover = 4, hopping = -U)
+// (y-slab: rows y0 .. y0 + Ly_l - 1 of a lattice of Ly_g rows, the links read from the GLOBAL field as in k_wilson_fill_slab; the whole
+//  lattice is y0 = 0, Ly_l = Ly_g)
 __global__ __launch_bounds__(BLOCK) void k_nc1_fill(cplx* __restrict__ clover, cplx* __restrict__ hop,
-                                                    const cplx* __restrict__ g, int hr, int Ly, int mode) {
-  const long half_vol = (long)hr * Ly, vol = 2 * half_vol;
+                                                    const cplx* __restrict__ g, int hr, int Ly_g, int y0, int Ly_l, int mode) {
+  const long hv_l = (long)hr * Ly_l, vol = 2 * hv_l;
+  const long hv_g = (long)hr * Ly_g, vol_g = 2 * hv_g;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < vol; i += (long)gridDim.x * BLOCK) {
-    const int p = (int)(i / half_vol);
-    const long wi = i - (long)p * half_vol;
-    const int y = (int)(wi / hr), j = (int)(wi - (long)y * hr);
-    const cplx ux = g[i], uy = g[vol + i];
-    const cplx uxb = cconj(g[neighbour_site(QMG_CSHIFT_FROM_XM1, p, y, j, hr, Ly, half_vol)]);
-    const cplx uyb = cconj(g[vol + neighbour_site(QMG_CSHIFT_FROM_YM1, p, y, j, hr, Ly, half_vol)]);
+    const int p = (int)(i / hv_l);
+    const long wi = i - (long)p * hv_l;
+    const int yl = (int)(wi / hr), j = (int)(wi - (long)yl * hr);
+    const int y = y0 + yl;
+    const long gi = (long)p * hv_g + (long)y * hr + j;
+    const cplx ux = g[gi], uy = g[vol_g + gi];
+    const cplx uxb = cconj(g[neighbour_site(QMG_CSHIFT_FROM_XM1, p, y, j, hr, Ly_g, hv_g)]);
+    const cplx uyb = cconj(g[vol_g + neighbour_site(QMG_CSHIFT_FROM_YM1, p, y, j, hr, Ly_g, hv_g)]);
     if (mode == 0) {
       const double eta = ((y + p) & 1) ? -1.0 : 1.0;   // x = 2j + s, s = (y+p)&1
       hop[i] = cmake(-0.5 * ux.x, -0.5 * ux.y);
@@ -349,14 +354,30 @@ int qmg_wilson_fill_slab(void* clover, void* hopping, const void* gauge_global, 
 
 int qmg_staggered_fill(void* hopping, const void* gauge, int Lx, int Ly, void* stream) {
   if (!hopping || !gauge || !valid_lattice(Lx, Ly)) return QMG_ERR_INVALID;
-  k_nc1_fill<<<grid_1d((size_t)Lx * Ly), BLOCK, 0, as_stream(stream)>>>(nullptr, (cplx*)hopping, (const cplx*)gauge, Lx / 2, Ly, 0);
+  k_nc1_fill<<<grid_1d((size_t)Lx * Ly), BLOCK, 0, as_stream(stream)>>>(nullptr, (cplx*)hopping, (const cplx*)gauge, Lx / 2, Ly, 0, Ly, 0);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+// One y-slab of the staggered / gauged Laplace stencil (rows y0 .. y0 + Ly_local - 1, y0 even) from the GLOBAL gauge field, as qmg_wilson_fill_slab.
+int qmg_staggered_fill_slab(void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, void* stream) {
+  if (!hopping || !gauge_global || !valid_lattice(Lx, Ly_global) || !valid_lattice(Lx, Ly_local)) return QMG_ERR_INVALID;
+  if (y0 < 0 || (y0 & 1) || y0 + Ly_local > Ly_global) return QMG_ERR_INVALID;
+  k_nc1_fill<<<grid_1d((size_t)Lx * Ly_local), BLOCK, 0, as_stream(stream)>>>(nullptr, (cplx*)hopping, (const cplx*)gauge_global, Lx / 2, Ly_global, y0, Ly_local, 0);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+int qmg_laplace_fill_slab(void* clover, void* hopping, const void* gauge_global, int Lx, int Ly_global, int y0, int Ly_local, void* stream) {
+  if (!clover || !hopping || !gauge_global || !valid_lattice(Lx, Ly_global) || !valid_lattice(Lx, Ly_local)) return QMG_ERR_INVALID;
+  if (y0 < 0 || (y0 & 1) || y0 + Ly_local > Ly_global) return QMG_ERR_INVALID;
+  k_nc1_fill<<<grid_1d((size_t)Lx * Ly_local), BLOCK, 0, as_stream(stream)>>>((cplx*)clover, (cplx*)hopping, (const cplx*)gauge_global, Lx / 2, Ly_global, y0, Ly_local, 1);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
 
 int qmg_laplace_fill(void* clover, void* hopping, const void* gauge, int Lx, int Ly, void* stream) {
   if (!clover || !hopping || !gauge || !valid_lattice(Lx, Ly)) return QMG_ERR_INVALID;
-  k_nc1_fill<<<grid_1d((size_t)Lx * Ly), BLOCK, 0, as_stream(stream)>>>((cplx*)clover, (cplx*)hopping, (const cplx*)gauge, Lx / 2, Ly, 1);
+  k_nc1_fill<<<grid_1d((size_t)Lx * Ly), BLOCK, 0, as_stream(stream)>>>((cplx*)clover, (cplx*)hopping, (const cplx*)gauge, Lx / 2, Ly, 0, Ly, 1);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

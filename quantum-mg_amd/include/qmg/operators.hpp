@@ -109,11 +109,10 @@ struct EoPrecNc1 : public Stencil2D {
 // ---------------- Staggered (staggered.h) ----------------
 struct Staggered2D : public EoPrecNc1 {
   void update_links(complex<double>* gauge_links) {   // :81-123
-    if (qmg::slab().on && qmg::slab().world > 1) {   // only Wilson2D and the Galerkin operators are decomposed: refuse rather than fill a slab as if it were the lattice
-      std::cout << "[QMG-ERROR]: Staggered2D is not decomposed into y-slabs (facade slab mode serves Wilson2D and CoarseOperator2D).\n";
-      generated = false;
-      return;
-    }
+    if (qmg::slab().on)   // y-slab mode: gauge_links is the gauge field of the WHOLE lattice, this rank fills its rows
+      qmg::ok(qmg_staggered_fill_slab(hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1) * qmg::slab().world, qmg::slab().rank * lat->get_dim_mu(1),
+                                      lat->get_dim_mu(1), qmg::current_stream()), "qmg_staggered_fill_slab");
+    else
     qmg::ok(qmg_staggered_fill(hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1), qmg::current_stream()), "qmg_staggered_fill");
     drop_variants();
     generated = true;
@@ -145,11 +144,10 @@ inline void apply_eo_staggered_2D_M(complex<double>* lhs, complex<double>* rhs, 
 // ---------------- Gauged Laplace (gaugedlaplace.h) ----------------
 struct GaugedLaplace2D : public EoPrecNc1 {
   void update_links(complex<double>* gauge_links) {   // :77-115
-    if (qmg::slab().on && qmg::slab().world > 1) {
-      std::cout << "[QMG-ERROR]: GaugedLaplace2D is not decomposed into y-slabs (facade slab mode serves Wilson2D and CoarseOperator2D).\n";
-      generated = false;
-      return;
-    }
+    if (qmg::slab().on)   // y-slab mode: gauge_links is the gauge field of the WHOLE lattice
+      qmg::ok(qmg_laplace_fill_slab(clover, hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1) * qmg::slab().world, qmg::slab().rank * lat->get_dim_mu(1),
+                                    lat->get_dim_mu(1), qmg::current_stream()), "qmg_laplace_fill_slab");
+    else
     qmg::ok(qmg_laplace_fill(clover, hopping, gauge_links, lat->get_dim_mu(0), lat->get_dim_mu(1), qmg::current_stream()), "qmg_laplace_fill");
     drop_variants();
     generated = true;
