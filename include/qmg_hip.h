@@ -375,6 +375,7 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *   "stencil_nt"    bit 0: non-temporal loads of the stencil matrices, bit 1: non-temporal stores, nc <= 4 kernels (3)
  *   "stencil_pair"  0: one site per lane group (kernel A); 1 / 2: both parities of a column on 1 / 2 rows per lane group (2)
  *   "pair_prefetch" 1: fp64 batches with nc = 1 request system k+1's right-hand side ahead of system k's arithmetic (1)
+ *   "blas_nt_mb"    BLAS-1 kernels read their read-only operands non-temporally from vectors of this many MiB upwards, 0 = never (256)
  *   "stencil_rows"  cap on gridDim.y of the stencil kernels, 0 = one block row per lattice row (0)
  *   "stencil_mfma"  1: multi-rhs coarse applies (nc in 8,12,16,24,32; >= 4-5 systems) on the f64 matrix cores, 2-MFMA
  *                   packing for <= 8 systems; 2: plain 4-MFMA products; 0: vector-FMA kernel B only (1)
@@ -393,6 +394,7 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);
  *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)
  * (The ablation switch of tools/variants.py exists only in the tools build, `make DIAG=1`; this library has no such key.) */
+/* (QMG_TUNING="key=value,key=value" in the environment applies the same settings inside qmg_init -- for A/B runs of programs that do not call this.) */
 int qmg_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus

@@ -17,24 +17,33 @@ namespace qmg {
 constexpr int RED_BLOCKS = 1024;    // partials per reduction (4 blocks per CU)
 constexpr int RED_MAXK = 64;        // multidot width
 
+// vectors of at least this many bytes are streamed with non-temporal loads (tuning key "blas_nt_mb", in MiB; 0 = never)
+long g_blas_nt_bytes = 256l << 20;
+static inline bool blas_nt(size_t n_complex) { return g_blas_nt_bytes > 0 && (long)(n_complex * sizeof(cplx)) >= g_blas_nt_bytes; }
+
 // ---------------- streaming BLAS-1 ----------------
 enum BlasOp { OP_ZERO, OP_COPY, OP_CAX, OP_CAXY, OP_CAXPY, OP_CXPY, OP_CXPAY, OP_CAXPBY, OP_CXPYZ, OP_CAXPBYZ };
 
-template <int OP>
+// NT: the operands are read with the non-temporal hint.  A five-stream read of 12 GB runs at 6.96 TB/s with it and 6.37 without
+// (tools/membw4.hip; sc0 / sc1 make no difference), and a vector larger than the 256 MB Infinity Cache is gone before anyone reads it again
+// anyway -- so the launchers ask for it from `g_blas_nt_bytes` per vector upwards and leave smaller vectors to the caches.
+template <bool NT> __device__ __forceinline__ cplx ldx(const cplx* p, long i) { return NT ? ldc_nt<double>(p, i) : p[i]; }
+
+template <int OP, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_blas(cplx* __restrict__ z, const cplx* __restrict__ x, const cplx* __restrict__ y,
                                                 cplx a, cplx b, long n) {
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     cplx r;
     if (OP == OP_ZERO) r = cmake(0.0, 0.0);
-    else if (OP == OP_COPY) r = x[i];
-    else if (OP == OP_CAX) r = cmul(a, z[i]);
-    else if (OP == OP_CAXY) r = cmul(a, x[i]);
-    else if (OP == OP_CAXPY) { r = z[i]; cmac(r, a, x[i]); }
-    else if (OP == OP_CXPY) r = cadd(z[i], x[i]);
-    else if (OP == OP_CXPAY) { r = x[i]; cmac(r, a, z[i]); }
-    else if (OP == OP_CAXPBY) { r = cmul(b, z[i]); cmac(r, a, x[i]); }
-    else if (OP == OP_CXPYZ) r = cadd(x[i], y[i]);
-    else { r = cmul(a, x[i]); cmac(r, b, y[i]); }
+    else if (OP == OP_COPY) r = ldx<NT>(x, i);
+    else if (OP == OP_CAX) r = cmul(a, z[i]);                      // (z is written back: a non-temporal read of a line about to be stored loses 3 %)
+    else if (OP == OP_CAXY) r = cmul(a, ldx<NT>(x, i));
+    else if (OP == OP_CAXPY) { r = z[i]; cmac(r, a, ldx<NT>(x, i)); }
+    else if (OP == OP_CXPY) r = cadd(z[i], ldx<NT>(x, i));
+    else if (OP == OP_CXPAY) { r = ldx<NT>(x, i); cmac(r, a, z[i]); }
+    else if (OP == OP_CAXPBY) { r = cmul(b, z[i]); cmac(r, a, ldx<NT>(x, i)); }
+    else if (OP == OP_CXPYZ) r = cadd(ldx<NT>(x, i), ldx<NT>(y, i));
+    else { r = cmul(a, ldx<NT>(x, i)); cmac(r, b, ldx<NT>(y, i)); }
     z[i] = r;
   }
 }
@@ -42,10 +51,11 @@ __global__ __launch_bounds__(BLOCK) void k_blas(cplx* __restrict__ z, const cplx
 // y += sum_i a_i x_i for up to 32 vectors in ONE pass (GCR orthogonalisation: 2k separate caxpy launches -> 2)
 constexpr int MAXPY_K = 32;
 struct MultiAxpy { const cplx* x[MAXPY_K]; cplx a[MAXPY_K]; };
+template <bool NT>
 __global__ __launch_bounds__(BLOCK) void k_multi_caxpy(cplx* __restrict__ y, MultiAxpy m, int k, long n) {
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     cplx acc = y[i];
-    for (int j = 0; j < k; j++) cmac(acc, m.a[j], m.x[j][i]);
+    for (int j = 0; j < k; j++) cmac(acc, m.a[j], ldx<NT>(m.x[j], i));
     y[i] = acc;
   }
 }
@@ -120,18 +130,18 @@ __device__ __forceinline__ void block_reduce_store(double* v, double* partial_ou
   }
 }
 
-template <int OP>
+template <int OP, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_reduce(const cplx* __restrict__ x, const cplx* __restrict__ y, long n, double* __restrict__ partials) {
   double v[2] = {0.0, 0.0};
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
-    const cplx a = x[i];
+    const cplx a = ldx<NT>(x, i);
     if (OP == RED_NORM2) { v[0] = fma(a.x, a.x, v[0]); v[0] = fma(a.y, a.y, v[0]); }
     else if (OP == RED_DOT) {
-      const cplx b = y[i];
+      const cplx b = ldx<NT>(y, i);
       v[0] = fma(a.x, b.x, v[0]); v[0] = fma(a.y, b.y, v[0]);
       v[1] = fma(a.x, b.y, v[1]); v[1] = fma(-a.y, b.x, v[1]);
     } else if (OP == RED_DIFFNORM2) {
-      const cplx b = y[i];
+      const cplx b = ldx<NT>(y, i);
       const double dx = a.x - b.x, dy = a.y - b.y;
       v[0] = fma(dx, dx, v[0]); v[0] = fma(dy, dy, v[0]);
     } else {
@@ -163,16 +173,16 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_final(const double* __restrict
 
 struct MultiPtrs { const cplx* x[RED_MAXK]; };
 // k dots <x_i, y> in one pass over y: y[i] is loaded once per element and reused for all k vectors.
-template <int KT>
+template <int KT, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_multidot(MultiPtrs xs, int k0, const cplx* __restrict__ y, long n, double* __restrict__ partials, int ktot) {
   double v[2 * KT];
 #pragma unroll
   for (int q = 0; q < 2 * KT; q++) v[q] = 0.0;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
-    const cplx b = y[i];
+    const cplx b = ldx<NT>(y, i);
 #pragma unroll
     for (int q = 0; q < KT; q++) {
-      const cplx a = xs.x[k0 + q][i];
+      const cplx a = ldx<NT>(xs.x[k0 + q], i);
       v[2 * q] = fma(a.x, b.x, v[2 * q]); v[2 * q] = fma(a.y, b.y, v[2 * q]);
       v[2 * q + 1] = fma(a.x, b.y, v[2 * q + 1]); v[2 * q + 1] = fma(-a.y, b.x, v[2 * q + 1]);
     }
@@ -268,7 +278,8 @@ static int reduce2(const void* x, const void* y, size_t n, int width, double* ou
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   const unsigned g = red_grid((long)n);
-  k_reduce<OP><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
+  if (blas_nt(n)) k_reduce<OP, true><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
+  else k_reduce<OP, false><<<g, BLOCK, 0, st>>>((const cplx*)x, (const cplx*)y, (long)n, ws->partials);
   QMG_LAUNCH_CHECK();
   const bool dist = dist_reductions_on();   // slabs of one lattice: sum (max) over the ranks before the value leaves HBM
   double* res = out_dev ? out_dev : (dist ? ws->result : ws->pinned);
@@ -282,7 +293,8 @@ static int reduce2(const void* x, const void* y, size_t n, int width, double* ou
 template <int OP>
 static int blas_launch(void* z, const void* x, const void* y, cplx a, cplx b, size_t n, void* stream) {
   if (n == 0) return QMG_SUCCESS;
-  k_blas<OP><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((cplx*)z, (const cplx*)x, (const cplx*)y, a, b, (long)n);
+  if (blas_nt(n)) k_blas<OP, true><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((cplx*)z, (const cplx*)x, (const cplx*)y, a, b, (long)n);
+  else k_blas<OP, false><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((cplx*)z, (const cplx*)x, (const cplx*)y, a, b, (long)n);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }
@@ -346,7 +358,8 @@ int qmg_multi_caxpy(const double* coeffs, const void* const* xs, int k, void* y,
       m.x[j] = (const cplx*)xs[done + j];
       m.a[j] = make_double2(coeffs[2 * (done + j)], coeffs[2 * (done + j) + 1]);
     }
-    k_multi_caxpy<<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)y, m, kk, (long)n);
+    if (blas_nt(n)) k_multi_caxpy<true><<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)y, m, kk, (long)n);
+    else k_multi_caxpy<false><<<grid_1d(n), BLOCK, 0, as_stream(s)>>>((cplx*)y, m, kk, (long)n);
     QMG_LAUNCH_CHECK();
     done += kk;
   }
@@ -399,9 +412,11 @@ int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* 
   int k0 = 0;
   while (k0 < k) {   // chunks of 4 / 2 / 1 vectors: y is re-read once per chunk
     const int rem = k - k0;
-    if (rem >= 4) { k_multidot<4><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 4; }
-    else if (rem >= 2) { k_multidot<2><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 2; }
-    else { k_multidot<1><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += 1; }
+    const bool nt = blas_nt(n);
+#define QMG_MDOT(KT) { if (nt) k_multidot<KT, true><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); \
+                       else k_multidot<KT, false><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += KT; }
+    if (rem >= 4) QMG_MDOT(4) else if (rem >= 2) QMG_MDOT(2) else QMG_MDOT(1)
+#undef QMG_MDOT
     QMG_LAUNCH_CHECK();
   }
   const bool dist = dist_reductions_on();

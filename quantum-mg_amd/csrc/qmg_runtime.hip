@@ -2,6 +2,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <string>
+
 #include "qmg_common.h"
 
 namespace qmg {
@@ -44,6 +46,20 @@ int qmg_init(int device) {
   if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return QMG_ERR_NO_DEVICE;
   if (device < 0 || device >= c) return QMG_ERR_INVALID;
   QMG_HIP_CHECK(hipSetDevice(device));
+  // QMG_TUNING="key=value,key=value": qmg_set_tuning for programs that do not call it themselves (A/B runs of the drivers);
+  // an unknown key is an error, not a silently ignored typo
+  if (const char* t = getenv("QMG_TUNING")) {
+    std::string all(t);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string item = all.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      if (eq == std::string::npos || qmg_set_tuning(item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != QMG_SUCCESS) return QMG_ERR_INVALID;
+      pos = end + 1;
+    }
+  }
   return QMG_SUCCESS;
 }
 

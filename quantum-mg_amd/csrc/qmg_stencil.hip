@@ -1242,6 +1242,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "stencil_ablate")) { g_stencil_ablate = value; return QMG_SUCCESS; }
 #endif
   if (!strcmp(key, "stencil_pair")) { g_stencil_pair = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "blas_nt_mb")) { g_blas_nt_bytes = (long)value << 20; return QMG_SUCCESS; }
   if (!strcmp(key, "pair_prefetch")) { g_pair_prefetch = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_site")) { g_stencil_site = value; return QMG_SUCCESS; }
   if (!strcmp(key, "site_block")) { if (value != 64 && value != 128 && value != 256) return QMG_ERR_INVALID; g_site_block = value; return QMG_SUCCESS; }

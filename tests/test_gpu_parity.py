@@ -666,3 +666,28 @@ def test_transfer_at_4096_spot_checked():
             assert cs.rel_l2(fout.read(e0, fnc), wantf) < TOL, (x, y)
     for a in (nv, cv, fv, fout, cout):
         a.free()
+
+
+def test_blas_non_temporal_reads_change_no_bit():
+    """Vectors of `blas_nt_mb` MiB and more are streamed with non-temporal loads on their read-only operands (csrc/qmg_blas.hip): a cache hint,
+    so every BLAS-1 result and every reduction must be the same bits with the threshold at 1 MiB (on for these 4.8 MB vectors) and at 0 (never)."""
+    n = 300001
+    x, y, z0 = cs.gaussian_cvec(n, 41), cs.gaussian_cvec(n, 42), cs.gaussian_cvec(n, 43)
+    dx, dy = D(x), D(y)
+    res = {}
+    try:
+        for mb in (0, 1):
+            qmg.set_tuning("blas_nt_mb", mb)
+            out = []
+            for fn in (lambda z: qmg.caxpy(0.3 - 0.2j, dx, z, n), lambda z: qmg.cxpay(dx, 0.7 + 0.1j, z, n), lambda z: qmg.caxpbyz(0.3, dx, -1.1j, dy, z, n),
+                       lambda z: qmg.cxpy(dx, z, n), lambda z: qmg.multi_caxpy([0.1, 0.2j], [dx, dy], z, n)):
+                dz = D(z0)
+                fn(dz)
+                out.append(dz.to_host())
+            out.append(np.array([qmg.norm2sq(dx, n), qmg.diffnorm2sq(dx, dy, n), qmg.norminf(dx, n)]))
+            out.append(np.array([qmg.dot(dx, dy, n)] + list(qmg.multidot([dx, dy, D(z0)], dy, n))))
+            res[mb] = out
+    finally:
+        qmg.set_tuning("blas_nt_mb", 256)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
