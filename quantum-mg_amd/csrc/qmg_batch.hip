@@ -28,6 +28,17 @@ constexpr int BDOT_MAX = 32;         // vectors per batched multidot / multi_cax
 // 16-byte aligned with even n and stride, else 1).  Arithmetic is fp64 in registers for both T.
 struct BatchCoef { cplx a[BATCH_MAX], b[BATCH_MAX]; };   // indexed by system id
 
+// read-only operands of a batch whose active systems add up to `blas_nt_mb` MiB or more are streamed non-temporally (as in qmg_blas.hip:
+// +8-10 % on vectors the caches cannot hold anyway); the in/out operand never is.  A run-time, launch-uniform choice.
+template <typename T, int W>
+__device__ __forceinline__ void ldb(const void* p, long i, cplx (&v)[W], bool nt) {
+  if (nt) ldc_pack_nt<T, W>(p, i, v);
+  else ldc_pack<T, W>(p, i, v);
+}
+static inline int batch_nt(const BatchIdx& bi, size_t n, int dtype) {
+  return g_blas_nt_bytes > 0 && (long)((size_t)bi.n * n * (dtype == QMG_C32 ? 8 : 16)) >= g_blas_nt_bytes;
+}
+
 template <int OP, typename T, int W>
 __global__ __launch_bounds__(BLOCK) void k_bblas(void* __restrict__ z_, const void* __restrict__ x_, const void* __restrict__ y_, const BatchCoef c,
                                                  const BatchIdx bi, long n, long stride) {
@@ -41,8 +52,8 @@ __global__ __launch_bounds__(BLOCK) void k_bblas(void* __restrict__ z_, const vo
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
     cplx r[W], u[W], v[W];
     if (OP == QMG_BOP_CAX || OP == QMG_BOP_CAXPY || OP == QMG_BOP_CXPY) ldc_pack<T, W>(z, i, r);
-    if (OP == QMG_BOP_COPY || OP == QMG_BOP_CAXPY || OP == QMG_BOP_CXPY || OP == QMG_BOP_CAXPBYZ) ldc_pack<T, W>(x, i, u);
-    if (OP == QMG_BOP_CAXPBYZ) ldc_pack<T, W>(y, i, v);
+    if (OP == QMG_BOP_COPY || OP == QMG_BOP_CAXPY || OP == QMG_BOP_CXPY || OP == QMG_BOP_CAXPBYZ) ldb<T, W>(x, i, u, bi.nt);
+    if (OP == QMG_BOP_CAXPBYZ) ldb<T, W>(y, i, v, bi.nt && y_ != z_);   // (z = a x + b z is the common aliased use: then y is the in/out operand)
 #pragma unroll
     for (int w = 0; w < W; w++) {
       if (OP == QMG_BOP_ZERO) r[w] = cmake(0.0, 0.0);
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, c
       // directions): the slot may hold stale pool memory, which must not be read (0 * inf = nan)
       if (c.x != 0.0 || c.y != 0.0) {
         cplx u[W];
-        ldc_pack<T, W>(reinterpret_cast<const ct*>(m.x[j]) + off, i, u);
+        ldb<T, W>(reinterpret_cast<const ct*>(m.x[j]) + off, i, u, bi.nt);
 #pragma unroll
         for (int w = 0; w < W; w++) cmac(acc[w], c, u[w]);
       }
@@ -115,8 +126,8 @@ __global__ __launch_bounds__(BLOCK) void k_breduce(const void* __restrict__ x_, 
   const long np = n / W;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
     cplx av[W], bv[W];
-    ldc_pack<T, W>(x, i, av);
-    if (OP != QMG_BRED_NORM2) ldc_pack<T, W>(y, i, bv);
+    ldb<T, W>(x, i, av, bi.nt);
+    if (OP != QMG_BRED_NORM2) ldb<T, W>(y, i, bv, bi.nt);
 #pragma unroll
     for (int w = 0; w < W; w++) {
       const cplx a = av[w];
@@ -149,11 +160,11 @@ __global__ __launch_bounds__(BLOCK) void k_bmultidot(const BatchPtrs xs, int j0,
   const long np = n / W;
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
     cplx bv[W];
-    ldc_pack<T, W>(y, i, bv);
+    ldb<T, W>(y, i, bv, bi.nt);
 #pragma unroll
     for (int q = 0; q < KT; q++) {
       cplx av[W];
-      ldc_pack<T, W>(reinterpret_cast<const ct*>(xs.x[j0 + q]) + off, i, av);
+      ldb<T, W>(reinterpret_cast<const ct*>(xs.x[j0 + q]) + off, i, av, bi.nt);
 #pragma unroll
       for (int w = 0; w < W; w++) {
         const cplx a = av[w], b = bv[w];
@@ -242,8 +253,9 @@ int qmg_batch_blas_t(int dtype, int op, const double* a, const double* b, const 
   if ((op == QMG_BOP_COPY || op == QMG_BOP_CAXPY || op == QMG_BOP_CXPY || op == QMG_BOP_CAXPBYZ) && !x && n) return QMG_ERR_INVALID;
   if (op == QMG_BOP_CAXPBYZ && ((!y && n) || !b)) return QMG_ERR_INVALID;
   if ((op == QMG_BOP_CAX || op == QMG_BOP_CAXPY || op == QMG_BOP_CAXPBYZ) && !a) return QMG_ERR_INVALID;
-  const BatchIdx bi = expand_mask(mask, nrhs);
+  BatchIdx bi = expand_mask(mask, nrhs);
   if (bi.n == 0 || n == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
   BatchCoef c;
   for (int k = 0; k < BATCH_MAX; k++) {
     c.a[k] = (a && k < nrhs) ? make_double2(a[2 * k], a[2 * k + 1]) : make_double2(0.0, 0.0);
@@ -275,8 +287,9 @@ int qmg_batch_blas(int op, const double* a, const double* b, const void* x, cons
 int qmg_batch_multi_caxpy_t(int dtype, const double* coeffs, const void* const* xs, int nj, void* y, size_t n, int nrhs, size_t stride, unsigned mask,
                             void* stream) {
   if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || nj < 0 || (nj > 0 && (!coeffs || !xs)) || (!y && n)) return QMG_ERR_INVALID;
-  const BatchIdx bi = expand_mask(mask, nrhs);
+  BatchIdx bi = expand_mask(mask, nrhs);
   if (bi.n == 0 || n == 0 || nj == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
   int W = pack_width(dtype, n, stride, nrhs, {y});
   for (int j = 0; j < nj; j++) if (!xs[j]) return QMG_ERR_INVALID; else if (dtype == QMG_C32 && !aligned16(xs[j])) W = 1;
   dim3 grid(grid_1d(n / W), (unsigned)bi.n);
@@ -305,8 +318,9 @@ int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n
   if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || !x || !out_host) return QMG_ERR_INVALID;
   if (op < QMG_BRED_NORM2 || op > QMG_BRED_DIFFNORM2) return QMG_ERR_INVALID;
   if (op != QMG_BRED_NORM2 && !y) return QMG_ERR_INVALID;
-  const BatchIdx bi = expand_mask(mask, nrhs);
+  BatchIdx bi = expand_mask(mask, nrhs);
   if (bi.n == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
   BatchWorkspace* ws;
   int rc = get_bws(&ws);
   if (rc) return rc;
@@ -343,8 +357,9 @@ int qmg_batch_reduce(int op, const void* x, const void* y, size_t n, int nrhs, s
 int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask, double* out_host,
                          void* stream) {
   if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || nj < 1 || nj > BDOT_MAX || !xs || !y || !out_host) return QMG_ERR_INVALID;
-  const BatchIdx bi = expand_mask(mask, nrhs);
+  BatchIdx bi = expand_mask(mask, nrhs);
   if (bi.n == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
   BatchWorkspace* ws;
   int rc = get_bws(&ws);
   if (rc) return rc;

@@ -181,10 +181,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // ---------------- lock-step batches: the active systems of a call ----------------
 constexpr int BATCH_MAX = 16;
-struct BatchIdx { int n; unsigned char id[BATCH_MAX]; };
+struct BatchIdx { int n; int nt; unsigned char id[BATCH_MAX]; };   // nt: the batch is large enough for non-temporal reads (qmg_batch.hip)
 inline BatchIdx expand_mask(unsigned mask, int nrhs) {
   BatchIdx b;
   b.n = 0;
+  b.nt = 0;
   for (int k = 0; k < nrhs && k < BATCH_MAX; k++)
     if ((mask >> k) & 1u) b.id[b.n++] = (unsigned char)k;
   for (int k = b.n; k < BATCH_MAX; k++) b.id[k] = 0;

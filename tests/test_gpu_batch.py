@@ -257,3 +257,39 @@ def test_batch_entry_points_edge_cases():
     assert L.qmg_stencil_apply_batch(C.byref(d), C.c_void_p(dy.ptr), C.c_void_p(dx.ptr), C.c_uint(0xFFF), 4, C.c_size_t(8 * 8 * 8), C.c_uint(0), None) == 0   # empty mask
     free_b, total_b = C.c_size_t(0), C.c_size_t(0)
     assert L.qmg_mem_info(C.byref(free_b), C.byref(total_b)) == 0 and 0 < free_b.value <= total_b.value and total_b.value > 200e9   # 288 GB part
+
+
+@pytest.mark.parametrize("dtype", ["c64", "c32"])
+def test_batch_non_temporal_reads_change_no_bit(dtype):
+    """A batch whose active systems add up to `blas_nt_mb` MiB reads its read-only operands non-temporally (csrc/qmg_batch.hip): the same
+    bits with the threshold at 1 MiB (on: 5 systems x 100 001 elements) and at 0 (never), in both storage precisions, aliased z = a x + b z included."""
+    n, nrhs, mask = 100001, 5, 0b10111
+    stride = n + 3
+    np_t = np.complex128 if dtype == "c64" else np.complex64
+    dt = qmg.C64 if dtype == "c64" else qmg.C32
+    mk = lambda seed: qmg.DeviceArray.from_host(cs.gaussian_cvec(stride * nrhs, seed).astype(np_t))
+    x, y = mk(1), mk(2)
+    z0 = cs.gaussian_cvec(stride * nrhs, 3).astype(np_t)
+    a, b = cs.gaussian_cvec(nrhs, 4), cs.gaussian_cvec(nrhs, 5)
+    res = {}
+    try:
+        for mb in (0, 1):
+            qmg.set_tuning("blas_nt_mb", mb)
+            out = []
+            for op, kw in ((qmg.BOP_CAXPY, dict(a=a, x=x)), (qmg.BOP_CAXPBYZ, dict(a=a, b=b, x=x, y=y)), (qmg.BOP_COPY, dict(x=x))):
+                z = qmg.DeviceArray.from_host(z0)
+                qmg.batch_blas_t(dt, op, z, n, nrhs, stride, mask, **kw)
+                out.append(z.to_host())
+            z = qmg.DeviceArray.from_host(z0)
+            qmg.batch_blas_t(dt, qmg.BOP_CAXPBYZ, z, n, nrhs, stride, mask, a=a, b=b, x=x, y=z)      # z = a x + b z
+            out.append(z.to_host())
+            z = qmg.DeviceArray.from_host(z0)
+            qmg.batch_multi_caxpy_t(dt, np.outer(np.array([0.3, -0.2j]), a), [x, y], z, n, nrhs, stride, mask)
+            out.append(z.to_host())
+            out.append(np.nan_to_num(qmg.batch_reduce_t(dt, qmg.BRED_DOT, x, y, n, nrhs, stride, mask)))
+            out.append(np.nan_to_num(qmg.batch_multidot_t(dt, [x, y], y, n, nrhs, stride, mask)))
+            res[mb] = out
+    finally:
+        qmg.set_tuning("blas_nt_mb", 256)
+    for u, v in zip(res[0], res[1]):
+        assert np.array_equal(u, v)
