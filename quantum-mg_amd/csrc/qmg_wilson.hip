@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
     const gchar* gyE_dn = uni(gc + (gvol + (long)gym * a.hr) * GB);                 // Uy of the EVEN sites of row y-1: the odd site's back-y link
     const gchar* gyO_dn = uni(gc + (gvol + a.ghalf_vol + (long)gym * a.hr) * GB);   // ... of the ODD sites: the even site's
     typedef typename std::conditional<F64, w2d, w2f>::type LK;
-    const LK uxE = gld<LK>(gxE, goff_j), uxO = gld<LK>(gxO, goff_j), uyE = gld_nt<LK>(gyE, goff_j), uyO = gld_nt<LK>(gyO, goff_j);
+    const LK uxE = gld<LK>(gxE, goff_j), uxO = gld<LK>(gxO, goff_j), uyE = gld<LK>(gyE, goff_j), uyO = gld<LK>(gyO, goff_j);
     const LK ubx = gld<LK>(sE ? gxE : gxO, goff_l);     // sE = 0: Ux of the odd site at j-1 (the even site's back-x); sE = 1: Ux of the even site at j-1
     const LK ubyE = gld<LK>(gyO_dn, goff_j), ubyO = gld<LK>(gyE_dn, goff_j);
     __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
     const gchar* gyE_dn = uni(gc + (gvol + (long)gym * a.hr) * GB);
     const gchar* gyO_dn = uni(gc + (gvol + a.ghalf_vol + (long)gym * a.hr) * GB);
     const LK uxEA = gld<LK>(gxEA, goff_j), uxOA = gld<LK>(gxOA, goff_j), uyEA = gld<LK>(gyEA, goff_j), uyOA = gld<LK>(gyOA, goff_j);
-    const LK uxEB = gld<LK>(gxEB, goff_j), uxOB = gld<LK>(gxOB, goff_j), uyEB = gld_nt<LK>(gyEB, goff_j), uyOB = gld_nt<LK>(gyOB, goff_j);
+    const LK uxEB = gld<LK>(gxEB, goff_j), uxOB = gld<LK>(gxOB, goff_j), uyEB = gld<LK>(gyEB, goff_j), uyOB = gld<LK>(gyOB, goff_j);
     const LK ubxA = gld<LK>(sA ? gxEA : gxOA, goff_l), ubxB = gld<LK>(sB ? gxEB : gxOB, goff_l);
     const LK ubyEA = gld<LK>(gyO_dn, goff_j), ubyOA = gld<LK>(gyE_dn, goff_j);
     __builtin_amdgcn_sched_barrier(0);
