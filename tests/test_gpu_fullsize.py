@@ -134,3 +134,27 @@ def test_c5_adaptive_schur_4096_fp64_and_fp32_kcycle(golden_dir):
     f = re.search(r"\[QMG-MRHS\]: rhs 0 converged in (\d+) iterations ; alleged tolerance [-\d.e+]+ ; check tolerance ([-\d.e+]+)", out.stdout)
     assert f and float(f.group(2)) <= 1.05e-10
     assert abs(int(f.group(1)) - it) <= max(4, it // 10)       # another right-hand side, fp32 preconditioner: about the same count
+
+
+def test_apply_norm2_wilson_2048_four_systems(golden_dir):
+    """qmg_stencil_apply_norm2 on the stored Wilson stencil (nc = 2) at 2048^2 for 4 systems: the bytes of qmg_stencil_apply, the norms of the
+    separate reductions to 1e-13 -- the size-independent properties of tests/test_gpu_apply_norm.py at a BASELINE size."""
+    import bench
+    L, nrhs = 2048, 4
+    fixture = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    wl = bench.Workload(qmg, L, fixture, 1337)
+    n = 2 * L * L
+    d = qmg.make_desc(L, L, 2, wl.clover, wl.hopping, bench.MASS)
+    rhs, a, b = qmg.DeviceArray(nrhs * n), qmg.DeviceArray(nrhs * n), qmg.DeviceArray(nrhs * n)
+    qmg.gaussian(rhs, nrhs * n, 5)
+    qmg.stencil_apply(d, a, rhs, qmg.P_ALL | qmg.P_ZERO, nrhs, n)
+    norms = qmg.stencil_apply_norm2(d, b, rhs, qmg.P_ALL | qmg.P_ZERO, nrhs, n)
+    for k in range(nrhs):
+        ref = qmg.norm2sq(a.offset(k * n), n)
+        assert abs(norms[k] - ref) <= 1e-13 * ref
+    qmg.batch_blas(qmg.BOP_CAXPY, b, n, nrhs, n, (1 << nrhs) - 1, a=[-1.0] * nrhs, x=a)      # b -= a: every byte equal <=> exactly zero
+    assert all(v == 0.0 for v in qmg.batch_reduce(qmg.BRED_NORM2, b, None, n, nrhs, n, (1 << nrhs) - 1).real)
+    for x in (rhs, a, b):
+        x.free()
+    wl.free()
+
