@@ -657,6 +657,64 @@ def kcycle_c5_shape():
         return {"error": repr(e)}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): THIS process becomes the launcher.  It starts
+    N fresh children -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would
+    set them -- before anything here has touched the GPU (no torch import, no HIP call: a process that has initialised HIP is
+    never re-executed), forwards rank 0's JSON line and returns the worst exit code.  A child that dies takes the others with
+    it (exact PIDs), so a failed rank cannot leave the rest waiting in a collective."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = ""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for pr in procs:
+            pr.wait()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+    for pr in procs:
+        if pr.returncode != 0:
+            rc = pr.returncode if pr.returncode > 0 else 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def launch_check(rank, world):
+    """Smallest end-to-end exercise of the launch path: every rank joins the process group the launcher's environment describes
+    (RCCL when a GPU is visible, gloo otherwise), ONE sum all-reduce of a one per rank, rank 0 prints what the collective saw.
+    `collective_ranks` == n_gpus proves that `world` ranks took part in a real collective.  CPU test: tests/test_distributed_cpu.py."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "collective_ranks": int(t.item()), "backend": dist.get_backend(),
+                          "group_world_size": dist.get_world_size()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -671,16 +729,23 @@ def main():
                          "kcycle: BASELINE configs[2] K-cycle, --nrhs independent systems per GPU in lock step, right-hand sides sharded over ranks (no collective)")
     ap.add_argument("--nrhs", type=int, default=8)
     ap.add_argument("--cpu-worker", nargs=2, metavar=("L", "BUDGET_S"), help="internal: one CPU-oracle apply loop (cpu_baseline_all_cores)")
+    ap.add_argument("--launch-check", action="store_true", help="only the launch path: N ranks join one process group (RCCL on GPUs, gloo on a CPU box), one all-reduce, one JSON line")
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(int(args.cpu_worker[0]), float(args.cpu_worker[1]))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher around us: be the launcher (before any GPU use)
+        import sys
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launch_check:
+        launch_check(rank, world)
+        return
 
     import torch
     dist = None
@@ -788,6 +853,29 @@ def main():
     # because counters cannot be read from inside the timed run -- and only if they belong to the kernel source in use
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(L)
     wl.free()
+
+    if world > 1 and dist is not None:
+        # (i) proof that `world` ranks met in a real RCCL collective; (ii) BASELINE configs[3]'s step on every rank: 8 right-hand sides
+        # per GPU, per-RHS norms from the apply pass, ONE all-reduce of world x 8 doubles per step (north_star: "a single RCCL all-reduce
+        # per global reduction over xGMI") -- the default workload above has no collective by construction
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones)
+        out["collective"] = {"backend": dist.get_backend(), "is_rccl": True, "group_world_size": dist.get_world_size(), "ranks_seen_by_allreduce": int(ones.item())}
+        if not args.no_also:
+            swl = StaggeredMultiRHS(qmg, 4096, fixture, 1337 + rank, 8, rank, world, dist, torch)
+            sgate = swl.parity_gate(fixture)
+            ssteps = max(10, args.steps // 4)
+            swall, skern = timed(qmg, swl, ssteps, args.warmup, barrier)
+            swall = sharding.max_over_ranks(swall, dist, "cuda")
+            srhs = 4096 * 4096 * 8
+            norms_host = swl.norms.cpu().numpy()
+            out["also_staggered_allreduce"] = {
+                "workload": "BASELINE configs[3]: staggered 4096x4096, %d right-hand sides = 8 per GPU x %d GPUs, apply + per-RHS norms + ONE all-reduce of %d doubles per step" % (8 * world, world, 8 * world),
+                "gflops_aggregate": world * srhs * swl.FLOP_PER_SITE_RHS * ssteps / swall / 1e9, "ms_per_step": swall / ssteps * 1e3, "steps": ssteps,
+                "kernel_ms_rank0": skern, "frac_of_hbm_peak_rank0": swl.bytes_per_site_rhs * srhs / (skern * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "parity_gate_rel_l2": sgate, "scaling": "weak",
+                "every_rank_sees_every_norm": bool((norms_host > 0).all()) and len(norms_host) == 8 * world}
+            swl.free()
 
     if rank == 0 and world == 1 and not args.no_also and L != 2048:
         wl2 = Workload(qmg, 2048, fixture, seed=1337)

@@ -95,6 +95,7 @@ const char* qmg_last_hip_error(void);
 const char* qmg_version(void);
 int qmg_malloc(void** dev_ptr, size_t bytes);   /* replaces allocate_vector<T> for device arrays */
 int qmg_free(void* dev_ptr);
+int qmg_shutdown(void);                         /* ordered teardown for the calling host thread: device sync, then the library's per-thread workspaces are released */
 int qmg_mem_info(size_t* free_bytes, size_t* total_bytes);   /* HBM free / total on the current device: batch sizing */
 int qmg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);  /* synchronous when stream == NULL */
 int qmg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
@@ -393,6 +394,8 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
  *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);
  *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)
+ *   "malloc_poison" 1: qmg_malloc fills every allocation with 0xFF bytes (NaNs in every storage precision): a buffer read before
+ *                   it is written then shows deterministically (0)
  * (The ablation switch of tools/variants.py exists only in the tools build, `make DIAG=1`; this library has no such key.) */
 /* (QMG_TUNING="key=value,key=value" in the environment applies the same settings inside qmg_init -- for A/B runs of programs that do not call this.) */
 int qmg_set_tuning(const char* key, int value);

@@ -32,7 +32,7 @@ EO_FROM_EVEN, EO_FROM_ODD, EO_FROM_EVENODD = 1, 2, 3
 # every symbol include/qmg_hip.h declares (checked by tests/test_abi_symbols.py against the header text)
 ABI_SYMBOLS = [
     "qmg_init", "qmg_device_count", "qmg_status_string", "qmg_last_hip_error", "qmg_version",
-    "qmg_malloc", "qmg_free", "qmg_mem_info", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
+    "qmg_malloc", "qmg_free", "qmg_shutdown", "qmg_mem_info", "qmg_memcpy_h2d", "qmg_memcpy_d2h", "qmg_memcpy_d2d", "qmg_memset_zero",
     "qmg_stream_create", "qmg_stream_destroy", "qmg_stream_sync",
     "qmg_event_create", "qmg_event_destroy", "qmg_event_record", "qmg_event_elapsed_ms", "qmg_stream_wait_event",
     "qmg_cshift", "qmg_stencil_apply", "qmg_stencil_apply_batch", "qmg_stencil_apply_mat32", "qmg_c64_to_c32", "qmg_wilson_fill", "qmg_staggered_fill", "qmg_laplace_fill",

@@ -217,6 +217,13 @@ static int get_bws(BatchWorkspace** out) {
   return QMG_SUCCESS;
 }
 
+void release_batch_workspace() {   // qmg_shutdown (qmg_runtime.hip)
+  if (g_bws.partials) hipFree(g_bws.partials);
+  if (g_bws.result) hipFree(g_bws.result);
+  if (g_bws.pinned) hipHostFree(g_bws.pinned);
+  g_bws = BatchWorkspace();
+}
+
 static unsigned bred_grid(long n) {
   long b = (n + BLOCK - 1) / BLOCK;
   if (b > BRED_BLOCKS) b = BRED_BLOCKS;

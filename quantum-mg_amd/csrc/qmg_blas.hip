@@ -245,6 +245,13 @@ static int get_ws(RedWorkspace** out) {
   return QMG_SUCCESS;
 }
 
+void release_blas_workspace() {   // qmg_shutdown (qmg_runtime.hip)
+  if (g_ws.partials) hipFree(g_ws.partials);
+  if (g_ws.result) hipFree(g_ws.result);
+  if (g_ws.pinned) hipHostFree(g_ws.pinned);
+  g_ws = RedWorkspace();
+}
+
 static unsigned red_grid(long n) {
   long b = (n + BLOCK - 1) / BLOCK;
   if (b > RED_BLOCKS) b = RED_BLOCKS;

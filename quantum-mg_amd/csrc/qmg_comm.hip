@@ -31,6 +31,8 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -55,7 +57,7 @@ struct Rccl {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool force = false;
-  bool dist_reduce = false;   // qmg_comm_set_distributed_reductions
+  std::atomic<bool> dist_reduce{false};   // qmg_comm_set_distributed_reductions (emulated ranks: written by every rank thread)
   bool load() {
     if (handle) return true;
     handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -87,32 +89,46 @@ struct ThreadWorld {
   std::condition_variable cv;
   int arrived = 0;
   long generation = 0;
+  bool aborted = false;                     // a rank failed inside a collective, or a barrier timed out: every later wait returns at once
   std::vector<const void*> vec;             // [rank]: the vector whose rows the current exchange sends
   std::vector<std::vector<double>> slot;    // [rank]: reduction operands
-  void barrier() {
+  // Bounded (QMG_COMM_TIMEOUT_S): false = the world is aborted -- a rank that failed before a collective never arrives, and the
+  // others must come back with an error, not wait for ever.
+  bool barrier(int timeout_seconds) {
     std::unique_lock<std::mutex> lk(m);
+    if (aborted) return false;
     const long gen = generation;
-    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
-    else cv.wait(lk, [&] { return generation != gen; });
+    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return true; }
+    const bool released = cv.wait_for(lk, std::chrono::seconds(timeout_seconds), [&] { return generation != gen || aborted; });
+    if (!released) { aborted = true; cv.notify_all(); return false; }
+    return !aborted || generation != gen;   // released by the last arrival: this barrier completed even if someone aborted right after
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
   }
 };
 static ThreadWorld g_tw;
+static int timeout_s() { const char* t = getenv("QMG_COMM_TIMEOUT_S"); const int v = t ? atoi(t) : 120; return v > 0 ? v : 120; }
+static int emu_fail(const char* what) { g_tw.abort(); set_hip_error(hipErrorUnknown, what); return QMG_ERR_HIP; }
 static thread_local int t_rank = -1;        // >= 0: this host thread is an emulated rank
 static inline bool emulated() { return t_rank >= 0 && g_tw.world > 0; }
 static inline int my_world() { return emulated() ? g_tw.world : g_rccl.world; }
 static inline int my_rank() { return emulated() ? t_rank : g_rccl.rank; }
 
-// in-place sum / max over the emulated ranks of n doubles in HBM
+// in-place sum / max over the emulated ranks of n doubles in HBM.  Never returns between the two barriers of the pair: a local
+// error is recorded, the world is aborted (every waiter comes back with an error), and the function leaves at the end.
 static int emulated_allreduce(double* buf_dev, int n, bool op_max, hipStream_t st) {
   std::vector<double>& mine = g_tw.slot[t_rank];
-  mine.resize((size_t)n);
-  QMG_HIP_CHECK(hipMemcpyAsync(mine.data(), buf_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-  QMG_HIP_CHECK(hipStreamSynchronize(st));
-  g_tw.barrier();
+  mine.assign((size_t)n, 0.0);
+  bool good = hipMemcpyAsync(mine.data(), buf_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (!good) g_tw.abort();
+  if (!g_tw.barrier(timeout_s())) return emu_fail("qmg_comm (emulated ranks): all-reduce aborted or timed out");
   std::vector<double> total((size_t)n, 0.0);
   for (int r = 0; r < g_tw.world; r++)      // rank order: every thread forms the same sum bit for bit
     for (int i = 0; i < n; i++) total[i] = (r == 0) ? g_tw.slot[r][i] : (op_max ? (g_tw.slot[r][i] > total[i] ? g_tw.slot[r][i] : total[i]) : total[i] + g_tw.slot[r][i]);
-  g_tw.barrier();                           // everyone has read every slot
+  if (!g_tw.barrier(timeout_s())) return emu_fail("qmg_comm (emulated ranks): all-reduce aborted or timed out");   // everyone has read every slot
   QMG_HIP_CHECK(hipMemcpyAsync(buf_dev, total.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
   QMG_HIP_CHECK(hipStreamSynchronize(st));   // `total` leaves scope
   return QMG_SUCCESS;
@@ -135,7 +151,6 @@ static double now_s() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
-static int timeout_s() { const char* t = getenv("QMG_COMM_TIMEOUT_S"); const int v = t ? atoi(t) : 120; return v > 0 ? v : 120; }
 
 static bool send_all(int fd, const void* buf, size_t n) {
   const char* p = (const char*)buf;
@@ -300,10 +315,11 @@ int qmg_comm_all_ok(int ok, int* all_ok) {
   *all_ok = ok ? 1 : 0;
   if (emulated()) {
     g_tw.slot[t_rank].assign(1, ok ? 0.0 : 1.0);
-    g_tw.barrier();
+    *all_ok = 0;
+    if (!g_tw.barrier(timeout_s())) return emu_fail("qmg_comm (emulated ranks): all_ok aborted or timed out");
     double bad_total = 0.0;
     for (int r = 0; r < g_tw.world; r++) bad_total += g_tw.slot[r][0];
-    g_tw.barrier();
+    if (!g_tw.barrier(timeout_s())) return emu_fail("qmg_comm (emulated ranks): all_ok aborted or timed out");
     *all_ok = (bad_total == 0.0) ? 1 : 0;
     return QMG_SUCCESS;
   }
@@ -354,50 +370,52 @@ int qmg_halo_exchange_parity(int dtype, const void* vec, int Lx, int Ly, int nc,
   if (nrhs > 1 && (vec_stride < 2 * half || halo_stride < 2 * row)) return QMG_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   const bool rccl = !emulated() && g_rccl.comm && (g_rccl.world > 1 || g_rccl.force);
+  // ONE plan for every transport (RCCL send / recv, thread-emulated ranks, one rank): who the neighbours are and, for system k
+  // and parity q, the byte offsets of the row that leaves a vector (its first / last row) and of the slot it lands in.
   const int up = (my_rank() + 1) % my_world(), down = (my_rank() + my_world() - 1) % my_world();
+  const size_t row_bytes = row * esz;
+  auto first_off = [&](int k, int q) { return ((size_t)k * vec_stride + (size_t)q * half) * esz; };                          // row y = 0 of parity q: becomes `down`'s halo_hi
+  auto last_off = [&](int k, int q) { return ((size_t)k * vec_stride + (size_t)q * half + (size_t)(Ly - 1) * row) * esz; };   // row y = Ly - 1: becomes `up`'s halo_lo
+  auto halo_off = [&](int k, int q) { return ((size_t)k * halo_stride + (size_t)q * row) * esz; };
   if (emulated()) {   // post my vector, fetch the neighbours' rows with device copies (same layout on every rank)
-    QMG_HIP_CHECK(hipStreamSynchronize(st));          // my rows are final
+    bool good = hipStreamSynchronize(st) == hipSuccess;          // my rows are final
     g_tw.vec[t_rank] = vec;
-    g_tw.barrier();
-    int erc = QMG_SUCCESS;
-    for (int k = 0; k < nrhs && erc == QMG_SUCCESS; k++)
+    if (!good) g_tw.abort();
+    if (!g_tw.barrier(timeout_s())) return emu_fail("qmg_comm (emulated ranks): halo exchange aborted or timed out");
+    for (int k = 0; k < nrhs && good; k++)
       for (int q = 0; q < 2; q++) {
         if (!((parities >> q) & 1u)) continue;
-        const char* vdn = (const char*)g_tw.vec[down] + (size_t)k * vec_stride * esz;   // down's LAST row is my row -1
-        const char* vup = (const char*)g_tw.vec[up] + (size_t)k * vec_stride * esz;     // up's FIRST row is my row Ly
-        char* lo = (char*)halo_lo + ((size_t)k * halo_stride + (size_t)q * row) * esz;
-        char* hi = (char*)halo_hi + ((size_t)k * halo_stride + (size_t)q * row) * esz;
-        if (hipMemcpyAsync(lo, vdn + ((size_t)q * half + (size_t)(Ly - 1) * row) * esz, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) erc = QMG_ERR_HIP;
-        if (hipMemcpyAsync(hi, vup + ((size_t)q * half) * esz, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) erc = QMG_ERR_HIP;
+        // down's LAST row is my row -1, up's FIRST row is my row Ly
+        if (hipMemcpyAsync((char*)halo_lo + halo_off(k, q), (const char*)g_tw.vec[down] + last_off(k, q), row_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) good = false;
+        if (hipMemcpyAsync((char*)halo_hi + halo_off(k, q), (const char*)g_tw.vec[up] + first_off(k, q), row_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) good = false;
       }
-    QMG_HIP_CHECK(hipStreamSynchronize(st));          // my copies are done ...
-    g_tw.barrier();                                    // ... and so are everybody's: the vectors may change again
-    return erc;
+    if (hipStreamSynchronize(st) != hipSuccess) good = false;     // my copies are done ...
+    if (!good) g_tw.abort();                                      // (recorded; the second barrier of the pair is still passed)
+    if (!g_tw.barrier(timeout_s()) || !good) return emu_fail("qmg_comm (emulated ranks): halo exchange failed");   // ... and so are everybody's: the vectors may change again
+    return QMG_SUCCESS;
   }
   const ncclDataType_t unit = ncclChar;
   if (rccl && g_rccl.group_start() != ncclSuccess) return QMG_ERR_HIP;
   int rc = QMG_SUCCESS;
-  for (int k = 0; k < nrhs && rc == QMG_SUCCESS; k++) {
-    const char* v = (const char*)vec + (size_t)k * vec_stride * esz;
-    char* lo = (char*)halo_lo + (size_t)k * halo_stride * esz;
-    char* hi = (char*)halo_hi + (size_t)k * halo_stride * esz;
+  for (int k = 0; k < nrhs && rc == QMG_SUCCESS; k++)
     for (int q = 0; q < 2; q++) {
       if (!((parities >> q) & 1u)) continue;
-      const char* first = v + ((size_t)q * half) * esz;                       // row y = 0 of parity q
-      const char* last = v + ((size_t)q * half + (size_t)(Ly - 1) * row) * esz;  // row y = Ly - 1
+      const char* first = (const char*)vec + first_off(k, q);
+      const char* last = (const char*)vec + last_off(k, q);
+      char* lo = (char*)halo_lo + halo_off(k, q);
+      char* hi = (char*)halo_hi + halo_off(k, q);
       if (rccl) {
         // order within the group: everything to / from `up` first, then `down`; with two ranks up == down and the
         // matching is by order per peer, so sends and receives are issued in the same (last, first) order on both sides
-        if (g_rccl.send(last, row * esz, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
-        if (g_rccl.send(first, row * esz, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
-        if (g_rccl.recv(lo + (size_t)q * row * esz, row * esz, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
-        if (g_rccl.recv(hi + (size_t)q * row * esz, row * esz, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
-      } else {
-        if (hipMemcpyAsync(lo + (size_t)q * row * esz, last, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
-        if (hipMemcpyAsync(hi + (size_t)q * row * esz, first, row * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.send(last, row_bytes, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.send(first, row_bytes, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.recv(lo, row_bytes, unit, down, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+        if (g_rccl.recv(hi, row_bytes, unit, up, g_rccl.comm, st) != ncclSuccess) rc = QMG_ERR_HIP;
+      } else {   // one rank: up == down == me, the periodic wrap
+        if (hipMemcpyAsync(lo, last, row_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
+        if (hipMemcpyAsync(hi, first, row_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = QMG_ERR_HIP;
       }
     }
-  }
   if (rccl && g_rccl.group_end() != ncclSuccess) return QMG_ERR_HIP;
   return rc;
 }
@@ -408,7 +426,7 @@ int qmg_halo_exchange_parity(int dtype, const void* vec, int Lx, int Ly, int nc,
 // distributed reductions see `world` ranks.
 int qmg_comm_emulate_begin(int world) {
   if (world < 1 || g_tw.world != 0) return QMG_ERR_INVALID;
-  g_tw.world = world; g_tw.arrived = 0; g_tw.generation = 0;
+  g_tw.world = world; g_tw.arrived = 0; g_tw.generation = 0; g_tw.aborted = false;
   g_tw.vec.assign((size_t)world, nullptr);
   g_tw.slot.assign((size_t)world, std::vector<double>());
   return QMG_SUCCESS;

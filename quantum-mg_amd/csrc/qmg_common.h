@@ -192,6 +192,11 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
   return b;
 }
 
+extern int g_malloc_poison;   // qmg_runtime.hip; "malloc_poison"
+// qmg_shutdown: the calling thread's reduction / norm workspaces (qmg_blas.hip, qmg_batch.hip, qmg_stencil.hip)
+void release_blas_workspace();
+void release_batch_workspace();
+void release_stencil_workspace();
 extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
 extern int g_wilson_pair;
 extern long g_blas_nt_bytes;   // qmg_blas.hip; "blas_nt_mb"   // qmg_wilson.hip; "wilson_pair"

@@ -7,6 +7,7 @@
 #include "qmg_common.h"
 
 namespace qmg {
+int g_malloc_poison = 0;   // tuning knob "malloc_poison"
 static thread_local char g_err[512] = "";
 void set_hip_error(hipError_t e, const char* where) {
   snprintf(g_err, sizeof(g_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
@@ -68,12 +69,29 @@ int qmg_malloc(void** p, size_t bytes) {
   *p = nullptr;
   if (bytes == 0) return QMG_SUCCESS;
   QMG_HIP_CHECK(hipMalloc(p, bytes));
+  // "malloc_poison": every byte 0xFF -- a complex<double> / complex<float> / complex<half> array then reads as NaNs, so a
+  // vector that is read before it is written shows up deterministically (in residuals, not as box-dependent behaviour)
+  if (g_malloc_poison) QMG_HIP_CHECK(hipMemset(*p, 0xFF, bytes));
   return QMG_SUCCESS;
 }
 
 int qmg_free(void* p) {
   if (!p) return QMG_SUCCESS;
   QMG_HIP_CHECK(hipFree(p));
+  return QMG_SUCCESS;
+}
+
+// Ordered teardown for the calling host thread: wait for the device, then release the library's per-thread workspaces
+// (reduction partials, pinned result slots).  Programs call it once per thread that used the library, after their last
+// call; the library stays usable (workspaces are re-created on demand).
+int qmg_shutdown(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return QMG_SUCCESS;   // nothing was ever initialised
+  QMG_HIP_CHECK(hipDeviceSynchronize());
+  release_blas_workspace();
+  release_batch_workspace();
+  release_stencil_workspace();
+  QMG_HIP_CHECK(hipDeviceSynchronize());
   return QMG_SUCCESS;
 }
 

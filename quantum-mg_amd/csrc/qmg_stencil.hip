@@ -1257,12 +1257,24 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "xfer_pack")) { g_xfer_pack = value; return QMG_SUCCESS; }
   if (!strcmp(key, "wilson_pair")) { g_wilson_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "setup_fused")) { g_setup_fused = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "malloc_poison")) { g_malloc_poison = value ? 1 : 0; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
                               const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0, const SlabHalo* slab = nullptr,
                               double* norms_dev = nullptr);
+
+// partials of the fused norms (one buffer per host thread = per rank, grown on demand) and the default result slot
+struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; double* own = nullptr; int own_dev = -1; };
+static thread_local NormWorkspace g_norm_ws;
+namespace qmg {
+void release_stencil_workspace() {   // qmg_shutdown (qmg_runtime.hip)
+  if (g_norm_ws.part) hipFree(g_norm_ws.part);
+  if (g_norm_ws.own) hipFree(g_norm_ws.own);
+  g_norm_ws = NormWorkspace();
+}
+}  // namespace qmg
 
 extern "C" int qmg_stencil_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                                  int nrhs, size_t vec_stride, void* stream) {
@@ -1310,14 +1322,13 @@ extern "C" int qmg_stencil_apply_norm2(const qmg_stencil_desc* d, void* lhs, con
   if (dist_reductions_on()) return QMG_ERR_UNSUPPORTED;
   if (!(pieces & (QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E)) || !(pieces & (QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O)))
     return QMG_ERR_UNSUPPORTED;   // a parity left untouched: its part of |lhs|^2 is not seen by the kernel
-  static thread_local double* own = nullptr;
-  static thread_local int own_dev = -1;
   double* res = norms_dev;
   if (!res) {
     int dev = 0;
     QMG_HIP_CHECK(hipGetDevice(&dev));
-    if (own_dev != dev) { QMG_HIP_CHECK(hipMalloc((void**)&own, sizeof(double) * 16)); own_dev = dev; }
-    res = own;
+    NormWorkspace& ws = g_norm_ws;
+    if (ws.own_dev != dev) { QMG_HIP_CHECK(hipMalloc((void**)&ws.own, sizeof(double) * 16)); ws.own_dev = dev; }
+    res = ws.own;
   }
   const int rc = stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 0, 0, nullptr, res);
   if (rc) return rc;
@@ -1344,10 +1355,6 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
   if (n == nrhs) return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 1, 1);
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1, 1);
 }
-
-// partials of the fused norms (one buffer per host thread = per rank, grown on demand)
-struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; };
-static thread_local NormWorkspace g_norm_ws;
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
                               const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab, double* norms_dev) {

@@ -16,6 +16,7 @@
 #include <unistd.h>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 
 using namespace std;
 
@@ -34,6 +35,7 @@ static double rel_resid(Stencil2D* op, complex<double>* x, complex<double>* b, l
 }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   const string gauge_file = (argc > 1) ? argv[1] : "../../tests/golden/l32t32b60_heatbath.dat";
   if (!qmg::ok(qmg_init(0), "qmg_init")) return 100;
   const int L = 32;
@@ -231,8 +233,34 @@ int main(int argc, char** argv) {
     delete[] nv;
   }
 
+  // ---- clear_stencils / prune_stencils on an operator that applies straight from the links: the cached link copy must
+  // not outlive the stored arrays.  Reference semantics (stencil_2d.h:339-404): after clear_stencils the matrices are zero, so
+  // apply_M adds shift * rhs and nothing else; after pruning the hopping term only clover + shift act.
+  {
+    const double m = 0.21;
+    complex<double>*v = allocate_vector<complex<double>>(n2), *a = allocate_vector<complex<double>>(n2), *w = allocate_vector<complex<double>>(n2);
+    gaussian(v, n2, 77);
+    {
+      Wilson2D wil(&lat2, m, gauge);
+      wil.clear_stencils();
+      zero_vector(a, n2); wil.apply_M(a, v);
+      caxy(m, v, w, n2);
+      check(diffnorm2sq(a, w, n2) <= 1e-28 * norm2sq(w, n2), "after clear_stencils apply_M is the shift term alone", sqrt(diffnorm2sq(a, w, n2) / norm2sq(w, n2)));
+      zero_vector(a, n2); apply_stencil_2D_M(a, v, (void*)&wil);
+      check(diffnorm2sq(a, w, n2) <= 1e-28 * norm2sq(w, n2), "after clear_stencils apply_stencil_2D_M is the shift term alone", sqrt(diffnorm2sq(a, w, n2) / norm2sq(w, n2)));
+    }
+    {
+      Wilson2D wil(&lat2, m, gauge);
+      wil.prune_stencils(QMG_PIECE_HOPPING);
+      zero_vector(a, n2); wil.apply_M(a, v);
+      caxy(2.0 + m, v, w, n2);   // Wilson clover = 2 w 1 (wilson.h:167-170), w = 1
+      check(diffnorm2sq(a, w, n2) <= 1e-28 * norm2sq(w, n2), "after pruning the hopping term apply_M is clover + shift", sqrt(diffnorm2sq(a, w, n2) / norm2sq(w, n2)));
+    }
+    for (complex<double>** p : {&v, &a, &w}) deallocate_vector(p);
+  }
+
   deallocate_vector(&gauge);
   qmg::VecPool::release_all();
   cout << (failures ? "[SELFTEST FAILED] " : "[SELFTEST PASSED] ") << failures << " failure(s)\n";
-  return failures;
+  return qmg_driver::leave(failures);
 }

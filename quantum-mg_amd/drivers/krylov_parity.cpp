@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 
 using namespace std;
 
@@ -54,6 +55,7 @@ static int host_cg(vector<complex<double>>& x, const vector<complex<double>>& b,
 }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   if (argc < 5) { cout << "usage: ./krylov_parity L mass gauge_file dump_dir\n"; return -1; }
   cout << setprecision(17);
   if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
@@ -111,5 +113,5 @@ int main(int argc, char** argv) {
   }
   deallocate_vector(&bl); deallocate_vector(&xl); deallocate_vector(&bnrm); deallocate_vector(&b); deallocate_vector(&x); deallocate_vector(&gauge);
   qmg::VecPool::release_all();
-  return 0;
+  return qmg_driver::leave(0);
 }

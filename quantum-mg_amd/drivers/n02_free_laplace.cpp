@@ -7,10 +7,12 @@
 #include <iostream>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 
 using namespace std;
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   cout << setiosflags(ios::fixed) << setprecision(6);
   if (!qmg::ok(qmg_init(0), "qmg_init")) return 2;
   const int x_len = 32, y_len = 24, dof = 1;
@@ -68,5 +70,5 @@ int main(int argc, char** argv) {
   deallocate_vector(&rhs); deallocate_vector(&lhs); deallocate_vector(&check_v);
   delete verb; delete lap_stencil; delete lat;
   qmg::VecPool::release_all();
-  return bad ? 1 : 0;
+  return qmg_driver::leave(bad ? 1 : 0);
 }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 
 using namespace std;
 
@@ -83,6 +84,7 @@ struct N13 {
            << " PostSmooth " << mg_object->get_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, i) << " Total " << mg_object->get_total_count(i) << "\n";
   }
   void destroy() {
+    qmg_driver::phase("teardown: multigrid objects", false);
     delete mg_object;
     for (int i = 0; i < n_refine; i++) { delete transfer_objs[i]; delete level_solve_objs[i]; }
     delete[] transfer_objs; delete[] level_solve_objs; delete coarsest_solve_obj;
@@ -147,6 +149,7 @@ inline int N13::build(int argc, char** argv) {
     for (int i = 0; i < n_refine && fits; i++) { fits = (rows % y_block == 0); rows /= y_block; fits = fits && !(rows & 1) && rows >= 2; }
     if (!fits) { if (root) std::cout << "[QMG-ERROR]: " << y_len << " rows do not split into " << world << " slabs of whole, even block rows on every level.\n"; return 4; }
   }
+  qmg_driver::phase("setup: gauge field", root);
   lats = new Lattice2D*[n_refine + 1];
   lats[0] = new Lattice2D(x_len, y_loc, dof);
   Lattice2D* lat_gauge = new Lattice2D(x_len, y_len, 1);
@@ -155,6 +158,7 @@ inline int N13::build(int argc, char** argv) {
   if (!got) return 3;
   delete lat_gauge;
 
+  qmg_driver::phase("setup: fine operator", root);
   auto t_setup0 = std::chrono::steady_clock::now();
   wilson_op = new Wilson2D(lats[0], mass, gauge_field);
   level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
@@ -176,6 +180,12 @@ inline int N13::build(int argc, char** argv) {
     const long fsize = lats[i - 1]->get_size_cv_l();
     complex<double>** null_vectors = new complex<double>*[coarse_dof];
     for (int j = 0; j < coarse_dof; j++) { null_vectors[j] = allocate_vector<complex<double>>(fsize); zero_vector(null_vectors[j], fsize); }
+    static const char* const phase_names[3][8] = {
+      {"setup: level 1 null vectors", "setup: level 2 null vectors", "setup: level 3 null vectors", "setup: level 4 null vectors", "setup: level 5 null vectors", "setup: level 6 null vectors", "setup: level 7 null vectors", "setup: level 8+ null vectors"},
+      {"setup: level 1 block orthonormalisation", "setup: level 2 block orthonormalisation", "setup: level 3 block orthonormalisation", "setup: level 4 block orthonormalisation", "setup: level 5 block orthonormalisation", "setup: level 6 block orthonormalisation", "setup: level 7 block orthonormalisation", "setup: level 8+ block orthonormalisation"},
+      {"setup: level 1 Galerkin build", "setup: level 2 Galerkin build", "setup: level 3 Galerkin build", "setup: level 4 Galerkin build", "setup: level 5 Galerkin build", "setup: level 6 Galerkin build", "setup: level 7 Galerkin build", "setup: level 8+ Galerkin build"}};
+    const int pl = (i - 1 < 7) ? i - 1 : 7;
+    qmg_driver::phase(phase_names[0][pl], root);
     auto t0 = now();
     if (null_batch > 1) {
       bool done = null_f32 ? relax_null_vectors_batched<float>(mg_object->get_stencil(i - 1), null_vectors, coarse_dof / 2, fsize, null_batch, seed)
@@ -211,8 +221,10 @@ inline int N13::build(int argc, char** argv) {
       fclose(f);
     }
     auto t1 = now();
+    qmg_driver::phase(phase_names[1][pl], root);
     transfer_objs[i - 1] = new TransferMG(lats[i - 1], lats[i], null_vectors, true, false, QMG_DOUBLE_PROJECTION);
     auto t2 = now();
+    qmg_driver::phase(phase_names[2][pl], root);
     level_solve_objs[i - 1] = new StatefulMultigridMG::LevelSolveMG;
     level_solve_objs[i - 1]->fine_stencil_app = QMG_MATVEC_ORIGINAL;
     level_solve_objs[i - 1]->intermediate_tol = inner_tol;

@@ -11,9 +11,10 @@
 #include "n13_setup.hpp"
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   N13 s;
   const int rc = s.build(argc, argv);
-  if (rc) return rc;
+  if (rc) return qmg_driver::leave(rc);
   Lattice2D** lats = s.lats;
   StatefulMultigridMG* mg_object = s.mg_object;
   const double tol = s.tol, setup_s = s.setup_s;
@@ -32,11 +33,13 @@ int main(int argc, char** argv) {
   complex<double>* Ax = mg_object->check_out(0);
   zero_vector(Ax, lats[0]->get_size_cv_l());
 
+  qmg_driver::phase("solve");
   auto t0 = std::chrono::steady_clock::now();
   invif = minv_vector_gcr_var_precond_restart(x, b, lats[0]->get_size_cv(), max_iter, tol, restart_freq, apply_stencil_2D_M, (void*)mg_object->get_stencil(0),
                                               StatefulMultigridMG::mg_preconditioner, (void*)mg_object, &verb);
   qmg_stream_sync(0);
   const double solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  qmg_driver::phase("check");
   cout << "Multigrid " << (invif.success ? "converged" : "failed to converge") << " in " << invif.iter << " iterations with alleged tolerance "
        << sqrt(invif.resSq) / bnorm << ".\n";
   zero_vector(Ax, lats[0]->get_size_cv_l());
@@ -55,5 +58,5 @@ int main(int argc, char** argv) {
 
   const bool ok_ = invif.success && true_res < 10 * tol;
   s.destroy();
-  return ok_ ? 0 : 1;
+  return qmg_driver::leave(ok_ ? 0 : 1);
 }

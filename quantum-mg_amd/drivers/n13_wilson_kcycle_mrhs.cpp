@@ -15,6 +15,7 @@
 static void n13_print_stats(void* p) { ((N13*)p)->print_ops_stats(); }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   if (argc < 9) { std::cout << "usage: ./n13_wilson_kcycle_mrhs L mass beta n_refine coarse_dof gauge_file tile nrhs [verify]\n"; return -1; }
   N13 s;
   const int rc = s.build(argc, argv);
@@ -29,5 +30,5 @@ int main(int argc, char** argv) {
   const bool ok_ = mrhs_solve_and_report(s.mg_object, s.lats[0], nrhs, s.seed + (unsigned long long)rank * nrhs, s.tol, s.max_iter, s.restart_freq, s.quiet, vmode, s.setup_s,
                                          n13_print_stats, (void*)&s, QMG_MATVEC_ORIGINAL, std::string(argv[argc - 1]) == "f32");
   s.destroy();
-  return ok_ ? 0 : 1;
+  return qmg_driver::leave(ok_ ? 0 : 1);
 }

@@ -112,28 +112,11 @@ static int run(int rank, int world, int device, int argc, char** argv) {
 }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
-  if (emulate > 0) {
-    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
-    std::vector<int> rc(emulate, 0);
-    std::vector<std::thread> th;
-    for (int r = 0; r < emulate; r++)
-      th.emplace_back([&, r] {
-        qmg_comm_emulate_attach(r);
-        void* st = 0;
-        qmg_stream_create(&st);
-        qmg::current_stream() = st;
-        rc[r] = run(r, emulate, 0, argc, argv);
-        qmg_stream_sync(st);
-        qmg::current_stream() = 0;
-        qmg_stream_destroy(st);
-      });
-    for (auto& t : th) t.join();
-    qmg_comm_emulate_end();
-    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
-    return 0;
-  }
+  if (emulate > 0)   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    return qmg_driver::leave(qmg_driver::emulate_ranks(emulate, [&](int r) { return run(r, emulate, 0, argc, argv); }, [](void* st) { qmg::current_stream() = st; }));
   const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
   const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
-  return run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, argc, argv);
+  return qmg_driver::leave(run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, argc, argv));
 }

@@ -16,10 +16,12 @@
 #include <vector>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 
 using namespace std;
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   if (argc < 5) { cout << "usage: ./n15_wilson_goldstone_u1_heatbath L mass beta n_meas [n_update n_therm seed [out_cfg]]\n"; return -1; }
   if (!qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
   const int x_len = stoi(argv[1]), y_len = x_len;
@@ -96,5 +98,5 @@ int main(int argc, char** argv) {
   deallocate_vector(&src); deallocate_vector(&prop); deallocate_vector(&phases); deallocate_vector(&gauge_field);
   delete wilson; delete lat_gauge; delete lat;
   qmg::VecPool::release_all();
-  return unconverged == 0 ? 0 : 1;
+  return qmg_driver::leave(unconverged == 0 ? 0 : 1);
 }

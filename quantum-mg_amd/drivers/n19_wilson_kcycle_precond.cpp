@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 #include "mrhs_solve.hpp"
 
 using namespace std;
@@ -191,29 +192,12 @@ static int run(int rank, int world, int device, bool slab_mode, int argc, char**
 }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
-  if (emulate > 0) {   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
-    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
-    std::vector<int> rc(emulate, 0);
-    std::vector<std::thread> th;
-    for (int r = 0; r < emulate; r++)
-      th.emplace_back([&, r] {
-        qmg_comm_emulate_attach(r);
-        void* st = 0;
-        qmg_stream_create(&st);
-        qmg::current_stream() = st;
-        rc[r] = run(r, emulate, 0, true, argc, argv);
-        qmg_stream_sync(st);
-        qmg::current_stream() = 0;
-        qmg_stream_destroy(st);
-      });
-    for (auto& t : th) t.join();
-    qmg_comm_emulate_end();
-    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
-    return 0;
-  }
+  if (emulate > 0)   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    return qmg_driver::leave(qmg_driver::emulate_ranks(emulate, [&](int r) { return run(r, emulate, 0, true, argc, argv); }, [](void* st) { qmg::current_stream() = st; }));
   const bool slab_mode = getenv("QMG_SLAB") != 0;
   const int rank = (slab_mode && getenv("RANK")) ? atoi(getenv("RANK")) : 0;
   const int world = (slab_mode && getenv("WORLD_SIZE")) ? atoi(getenv("WORLD_SIZE")) : 1;
-  return run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, slab_mode, argc, argv);
+  return qmg_driver::leave(run(rank, world, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0, slab_mode, argc, argv));
 }

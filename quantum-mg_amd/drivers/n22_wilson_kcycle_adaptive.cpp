@@ -36,6 +36,7 @@
 #include <ctime>
 
 #include "../include/qmg/qmg.hpp"
+#include "driver_common.hpp"
 #include "mrhs_solve.hpp"
 
 #include <vector>
@@ -395,32 +396,15 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
 }
 
 int main(int argc, char** argv) {
+  qmg_driver::Guard guard;
   if (argc < 6) {
     cout << "Error: ./wilson_kcycle expects five arguments, L, mass, beta, n_refine, n_setup. Try mass = -0.075 for beta 6.0.\n";
     return -1;
   }
   const int emulate = getenv("QMG_COMM_EMULATE") ? atoi(getenv("QMG_COMM_EMULATE")) : 0;
-  if (emulate > 0) {   // R slab ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
-    if (!qmg::ok(qmg_comm_emulate_begin(emulate), "qmg_comm_emulate_begin")) return 2;
-    std::vector<int> rc(emulate, 0);
-    std::vector<std::thread> th;
-    for (int r = 0; r < emulate; r++)
-      th.emplace_back([&, r] {
-        qmg_comm_emulate_attach(r);
-        void* st = 0;
-        qmg_stream_create(&st);
-        qmg::current_stream() = st;
-        rc[r] = run(r, emulate, 0, true, argc, argv);
-        qmg_stream_sync(st);
-        qmg::current_stream() = 0;
-        qmg_stream_destroy(st);
-      });
-    for (auto& t : th) t.join();
-    qmg_comm_emulate_end();
-    for (int r = 0; r < emulate; r++) if (rc[r]) return rc[r];
-    return 0;
-  }
+  if (emulate > 0)   // R ranks as host threads on this one GPU (csrc/qmg_comm.hip: ThreadWorld)
+    return qmg_driver::leave(qmg_driver::emulate_ranks(emulate, [&](int r) { return run(r, emulate, 0, true, argc, argv); }, [](void* st) { qmg::current_stream() = st; }));
   const bool slab_mode = getenv("QMG_SLAB") != 0;
-  return run(getenv("RANK") ? atoi(getenv("RANK")) : 0, getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0,
-             slab_mode, argc, argv);
+  return qmg_driver::leave(run(getenv("RANK") ? atoi(getenv("RANK")) : 0, getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0,
+             slab_mode, argc, argv));
 }

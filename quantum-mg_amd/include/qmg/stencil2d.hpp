@@ -185,7 +185,9 @@ struct Stencil2D {
     return true;
   }
   bool direct_usable(const complex<double>* cl, const complex<double>* ho) const {
-    return direct.on && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
+    // (the link copy stands in for the stored arrays only while those ARE the filled operator: clear_stencils / prune_stencils
+    // drop it, and a null pair -- 0 == 0 after a prune -- never qualifies)
+    return direct.on && generated && cl != 0 && ho != 0 && cl == clover && ho == hopping && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger && !f32_matrices;
   }
   // the hops of the right-block-Jacobi stencil, alone, while that stencil is the built one (swapped in or not)
   bool rbj_direct_usable(const complex<double>* cl, const complex<double>* ho, unsigned pieces) const {
@@ -350,6 +352,7 @@ struct Stencil2D {
       if (rbj_dagger_hopping != 0) zero_vector(rbj_dagger_hopping, lat->get_size_hopping_l());
       built_rbj_dagger = false;   // the reference resets built_rbjacobi here (:371), an apparent typo; the intent is kept
     }
+    drop_direct_links();   // the stored arrays are zero now: an apply must give the shift term only, not the operator of the cached links
     generated = false;
   }
 
@@ -358,6 +361,7 @@ struct Stencil2D {
     if ((pieces & QMG_PIECE_HOPPING) && hopping != 0) deallocate_vector(&hopping);
     if ((pieces & QMG_PIECE_TWOLINK) && twolink != 0) deallocate_vector(&twolink);
     if ((pieces & QMG_PIECE_CORNER) && corner != 0) deallocate_vector(&corner);
+    if (clover == 0 || hopping == 0) drop_direct_links();   // the link copy describes clover + hopping together
     if (clover == 0 && hopping == 0 && twolink == 0 && corner == 0) generated = false;
   }
 
@@ -366,6 +370,7 @@ struct Stencil2D {
     if ((pieces & QMG_PIECE_HOPPING) && hopping != 0 && norminf(hopping, lat->get_size_hopping_l()) < tol) deallocate_vector(&hopping);
     if ((pieces & QMG_PIECE_TWOLINK) && twolink != 0 && norminf(twolink, lat->get_size_hopping_l()) < tol) deallocate_vector(&twolink);
     if ((pieces & QMG_PIECE_CORNER) && corner != 0 && norminf(corner, lat->get_size_hopping_l()) < tol) deallocate_vector(&corner);
+    if (clover == 0 || hopping == 0) drop_direct_links();
     if (clover == 0 && hopping == 0 && twolink == 0 && corner == 0) generated = false;
   }
 

