@@ -207,6 +207,12 @@ int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* 
 /* reductions/reductions.h:24-87: per-timeslice (per-y) norm2sq / dot. out: Ly (or 2*Ly) doubles. */
 int qmg_norm2sq_cv_timeslice(const void* cv, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream);
 int qmg_dot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream);
+/* redot_cv_timeslice (reductions/reductions.h:47-66): sum[y] = Re sum_{x,c} conj(a) b, Ly doubles */
+int qmg_redot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream);
+/* gaussian_wall_source (reductions/reductions.h:90-162): cv = real Gaussian (mean + deviation N(0,1), imaginary part 0) on the elements with
+ * y == timeslice and component == color, zero elsewhere; QMG_ERR_INVALID for timeslice >= Ly or color >= nc (the reference prints and returns).
+ * The numbers come from the library's counter-based generator keyed by (seed, element index), not from std::mt19937 (see qmg_gaussian). */
+int qmg_gaussian_wall_source(void* cv, int Lx, int Ly, int nc, int timeslice, int color, unsigned long long seed, double deviation, double mean, void* stream);
 
 /* ---------------- transfer (transfer/transfer.h) ---------------- */
 /* Null vectors are passed as the reference holds them: nvec fine vectors, vector-major

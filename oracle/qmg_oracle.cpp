@@ -455,6 +455,45 @@ void qo_dot_cv_timeslice(double* sum, const double* a_, const double* b_, int Lx
   }
 }
 
+void qo_redot_cv_timeslice(double* sum, const double* a_, const double* b_, int Lx, int Ly, int nc) {   // reductions.h:47-66
+  const cplx* a = C(a_); const cplx* b = C(b_);
+  for (int t = 0; t < Ly; t++) sum[t] = 0.0;
+  const long size_cv = (long)Lx * Ly * nc;
+  for (long i = 0; i < size_cv; i++) {
+    int x, y;
+    qo_index_to_coord(Lx, Ly, (int)(i / nc), &x, &y);
+    sum[y] += std::real(std::conj(a[i]) * b[i]);
+  }
+}
+
+// gaussian_wall_source (reductions.h:90-162): loop over every element, cv_index_to_coord, a real draw where c == color and
+// y == timeslice, zero elsewhere.  Draw of element i: splitmix64 counter -> two uniforms -> Box-Muller (real part).
+static unsigned long long qo_splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+int qo_gaussian_wall_source(double* cv_, int Lx, int Ly, int nc, int timeslice, int color, unsigned long long seed, double deviation, double mean) {
+  if (timeslice >= Ly || timeslice < 0) return -1;   // "[QMG-ERROR]: Cannot create gaussian wall source for t < Nt." (:94-98)
+  if (color >= nc || color < 0) return -1;           // (:101-105)
+  cplx* cv = C(cv_);
+  const long size_cv = (long)Lx * Ly * nc;
+  for (long i = 0; i < size_cv; i++) {
+    int x, y;
+    qo_index_to_coord(Lx, Ly, (int)(i / nc), &x, &y);
+    const int c = (int)(i % nc);
+    if (c == color && y == timeslice) {
+      const unsigned long long h1 = qo_splitmix64(seed * 0xD1342543DE82EF95ull + 2ull * (unsigned long long)i);
+      const unsigned long long h2 = qo_splitmix64(h1 + 2ull * (unsigned long long)i + 1ull);
+      const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+      const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+      cv[i] = cplx(mean + deviation * (std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2)), 0.0);
+    } else cv[i] = 0.0;
+  }
+  return 0;
+}
+
 // ---------------- transfer ----------------
 // build_mapping (transfer.h:410-448): for coarse site i (even-odd index), the fine cv indices of the
 // block [cx*bx,(cx+1)*bx) x [cy*by,(cy+1)*by) x nc_f, sorted ascending (the reference merge-sorts, :440).

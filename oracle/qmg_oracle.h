@@ -103,6 +103,10 @@ double qo_norminf(const double* x, long n);
 /* reductions/reductions.h:24-87 */
 void qo_norm2sq_cv_timeslice(double* sum, const double* cv, int Lx, int Ly, int nc);
 void qo_dot_cv_timeslice(double* sum /*2*Ly*/, const double* a, const double* b, int Lx, int Ly, int nc);
+void qo_redot_cv_timeslice(double* sum /*Ly*/, const double* a, const double* b, int Lx, int Ly, int nc);   /* :47-66 */
+/* reductions/reductions.h:90-162; the draw of element i is the counter-based normal keyed by (seed, i) (the reference's std::mt19937 +
+ * std::normal_distribution stream is not portable); returns -1 (and leaves cv untouched) for timeslice >= Ly or color >= nc */
+int qo_gaussian_wall_source(double* cv, int Lx, int Ly, int nc, int timeslice, int color, unsigned long long seed, double deviation, double mean);
 
 /* ---- transfer/transfer.h ---- */
 /* coarse_map[i][j], ascending fine cv indices; returns fine_sites_per_coarse (transfer.h:386-448) */

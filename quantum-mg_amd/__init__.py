@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "qmg_zero_vector", "qmg_copy_vector", "qmg_cax", "qmg_caxy", "qmg_caxpy", "qmg_cxpy", "qmg_cxpay",
     "qmg_caxpby", "qmg_cxpyz", "qmg_caxpbyz", "qmg_multi_caxpy", "qmg_caxy_pattern", "qmg_gaussian",
     "qmg_norm2sq", "qmg_dot", "qmg_diffnorm2sq", "qmg_norminf", "qmg_multidot",
-    "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice",
+    "qmg_norm2sq_cv_timeslice", "qmg_dot_cv_timeslice", "qmg_redot_cv_timeslice", "qmg_gaussian_wall_source",
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_orthonormalize_n", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
@@ -235,6 +235,11 @@ def build_rbjacobi(cinv, rclover, rhopping, desc, stream=None):
     check(lib().qmg_build_rbjacobi(_vp(cinv), _vp(rclover), _vp(rhopping), C.byref(desc), C.c_void_p(stream)), "qmg_build_rbjacobi")
 
 
+def cmat_conjtrans(out, inp, nsite, nc, stream=None):
+    """out[i] = in[i]^dagger for nsite row-major nc x nc blocks (cMATcopy_conjtrans_square; stencil_2d.h:2012-2020: cinv of the rbj-dagger stencil)."""
+    check(lib().qmg_cmat_conjtrans(_vp(out), _vp(inp), C.c_size_t(nsite), nc, C.c_void_p(stream)), "qmg_cmat_conjtrans")
+
+
 def _scalar(a):
     a = complex(a)
     return C.c_double(a.real), C.c_double(a.imag)
@@ -340,6 +345,17 @@ def dot_cv_timeslice(a, b, Lx, Ly, nc):
     out = np.zeros(2 * Ly)
     check(lib().qmg_dot_cv_timeslice(_vp(a), _vp(b), Lx, Ly, nc, None, out.ctypes.data_as(C.POINTER(C.c_double)), None))
     return out[0::2] + 1j * out[1::2]
+
+
+def redot_cv_timeslice(a, b, Lx, Ly, nc):
+    out = np.zeros(Ly)
+    check(lib().qmg_redot_cv_timeslice(_vp(a), _vp(b), Lx, Ly, nc, None, out.ctypes.data_as(C.POINTER(C.c_double)), None))
+    return out
+
+
+def gaussian_wall_source(cv, Lx, Ly, nc, timeslice, color, seed, deviation=1.0, mean=0.0):
+    """reductions/reductions.h:90-162; returns the status instead of raising for an out-of-range timeslice / color (the reference prints and returns)."""
+    return lib().qmg_gaussian_wall_source(_vp(cv), Lx, Ly, nc, timeslice, color, C.c_ulonglong(seed), C.c_double(deviation), C.c_double(mean), None)
 
 
 def prolong(nullvecs, nvec, coarse, fine, fdims, cdims):

@@ -172,6 +172,26 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_final(const double* __restrict
   }
 }
 
+// gaussian_wall_source (reductions/reductions.h:90-162): a REAL Gaussian (mean + deviation N(0,1), imaginary part 0) on the elements with
+// y == timeslice and component == color, zero everywhere else.  The draw of element i is the real Box-Muller value k_gaussian gives it.
+__global__ __launch_bounds__(BLOCK) void k_wall_source(cplx* __restrict__ x, int hr, int Ly, int nc, int timeslice, int color, unsigned long long seed, double deviation, double mean) {
+  const long n = 2l * hr * Ly * nc;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long site = i / nc;
+    const int c = (int)(i - site * nc);
+    const int y = (int)((site / hr) % Ly);   // site = (y + p Ly) hr + j
+    cplx v = cmake(0.0, 0.0);
+    if (c == color && y == timeslice) {
+      const unsigned long long h1 = splitmix64(seed * 0xD1342543DE82EF95ull + 2ull * (unsigned long long)i);
+      const unsigned long long h2 = splitmix64(h1 + 2ull * (unsigned long long)i + 1ull);
+      const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+      const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+      v.x = mean + deviation * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2));
+    }
+    x[i] = v;
+  }
+}
+
 struct MultiPtrs { const cplx* x[RED_MAXK]; };
 // k dots <x_i, y> in one pass over y: y[i] is loaded once per element and reused for all k vectors.
 template <int KT, bool NT>
@@ -193,7 +213,8 @@ __global__ __launch_bounds__(BLOCK) void k_multidot(MultiPtrs xs, int k0, const 
 
 // per-timeslice reductions (reductions/reductions.h:24-87): sum over x and c for each y.
 // In the even-odd layout row y is two contiguous runs (one per parity) of hr*nc elements.
-template <bool DOT>
+// MODE 0: |a|^2 (norm2sq_cv_timeslice, :24-41); 1: conj(a) b, re and im (dot_cv_timeslice, :69-87); 2: Re conj(a) b (redot_cv_timeslice, :47-66)
+template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_timeslice(const cplx* __restrict__ a, const cplx* __restrict__ b, int hr, int Ly, int nc, double* __restrict__ out) {
   const int y = blockIdx.x;
   const long half_cv = (long)hr * Ly * nc;
@@ -201,13 +222,13 @@ __global__ __launch_bounds__(BLOCK) void k_timeslice(const cplx* __restrict__ a,
   double v[2] = {0.0, 0.0};
   for (int p = 0; p < 2; p++) {
     const cplx* ap = a + p * half_cv + (long)y * run;
-    const cplx* bp = DOT ? b + p * half_cv + (long)y * run : nullptr;
+    const cplx* bp = MODE ? b + p * half_cv + (long)y * run : nullptr;
     for (long i = threadIdx.x; i < run; i += BLOCK) {
       const cplx u = ap[i];
-      if (DOT) {
+      if (MODE) {
         const cplx w = bp[i];
         v[0] = fma(u.x, w.x, v[0]); v[0] = fma(u.y, w.y, v[0]);
-        v[1] = fma(u.x, w.y, v[1]); v[1] = fma(-u.y, w.x, v[1]);
+        if (MODE == 1) { v[1] = fma(u.x, w.y, v[1]); v[1] = fma(-u.y, w.x, v[1]); }
       } else { v[0] = fma(u.x, u.x, v[0]); v[0] = fma(u.y, u.y, v[0]); }
     }
   }
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_timeslice(const cplx* __restrict__ a,
   __syncthreads();
   part[0] = res[0]; part[1] = res[1];
   if (threadIdx.x == 0) {
-    if (DOT) { out[2 * y] = part[0]; out[2 * y + 1] = part[1]; }
+    if (MODE == 1) { out[2 * y] = part[0]; out[2 * y + 1] = part[1]; }
     else out[y] = part[0];
   }
 }
@@ -403,6 +424,14 @@ int qmg_gaussian_slab(void* x, int Lx, int Ly_global, int y0, int Ly_local, int 
   return QMG_SUCCESS;
 }
 
+int qmg_gaussian_wall_source(void* cv, int Lx, int Ly, int nc, int timeslice, int color, unsigned long long seed, double deviation, double mean, void* s) {
+  if (!cv || !valid_lattice(Lx, Ly) || nc < 1) return QMG_ERR_INVALID;
+  if (timeslice < 0 || timeslice >= Ly || color < 0 || color >= nc) return QMG_ERR_INVALID;   // the facade prints the reference's messages (:94-107)
+  k_wall_source<<<grid_1d((size_t)Lx * Ly * nc), BLOCK, 0, as_stream(s)>>>((cplx*)cv, Lx / 2, Ly, nc, timeslice, color, seed, deviation, mean);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
 int qmg_norm2sq(const void* x, size_t n, double* od, double* oh, void* s) { return reduce2<RED_NORM2>(x, nullptr, n, 1, od, oh, s); }
 int qmg_dot(const void* x, const void* y, size_t n, double* od, double* oh, void* s) { return reduce2<RED_DOT>(x, y, n, 2, od, oh, s); }
 int qmg_diffnorm2sq(const void* x, const void* y, size_t n, double* od, double* oh, void* s) { return reduce2<RED_DIFFNORM2>(x, y, n, 1, od, oh, s); }
@@ -441,7 +470,7 @@ int qmg_norm2sq_cv_timeslice(const void* cv, int Lx, int Ly, int nc, double* out
   double* res = out_dev;
   double* tmp = nullptr;
   if (!res) { QMG_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * Ly)); res = tmp; }
-  k_timeslice<false><<<Ly, BLOCK, 0, st>>>((const cplx*)cv, nullptr, Lx / 2, Ly, nc, res);
+  k_timeslice<0><<<Ly, BLOCK, 0, st>>>((const cplx*)cv, nullptr, Lx / 2, Ly, nc, res);
   QMG_LAUNCH_CHECK();
   int rc = finish(res, Ly, nullptr, out_host, st);
   if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
@@ -454,9 +483,23 @@ int qmg_dot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, d
   double* res = out_dev;
   double* tmp = nullptr;
   if (!res) { QMG_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * 2 * Ly)); res = tmp; }
-  k_timeslice<true><<<Ly, BLOCK, 0, st>>>((const cplx*)a, (const cplx*)b, Lx / 2, Ly, nc, res);
+  k_timeslice<1><<<Ly, BLOCK, 0, st>>>((const cplx*)a, (const cplx*)b, Lx / 2, Ly, nc, res);
   QMG_LAUNCH_CHECK();
   int rc = finish(res, 2 * Ly, nullptr, out_host, st);
+  if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
+  return rc;
+}
+
+// redot_cv_timeslice (reductions.h:47-66): sum[y] = Re sum_{x,c} conj(a) b -- Ly doubles
+int qmg_redot_cv_timeslice(const void* a, const void* b, int Lx, int Ly, int nc, double* out_dev, double* out_host, void* stream) {
+  if (!a || !b || !valid_lattice(Lx, Ly) || nc < 1 || (!out_dev && !out_host)) return QMG_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  double* res = out_dev;
+  double* tmp = nullptr;
+  if (!res) { QMG_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * Ly)); res = tmp; }
+  k_timeslice<2><<<Ly, BLOCK, 0, st>>>((const cplx*)a, (const cplx*)b, Lx / 2, Ly, nc, res);
+  QMG_LAUNCH_CHECK();
+  int rc = finish(res, Ly, nullptr, out_host, st);
   if (tmp) { hipStreamSynchronize(st); hipFree(tmp); }
   return rc;
 }

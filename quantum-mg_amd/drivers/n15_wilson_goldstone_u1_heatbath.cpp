@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
         inversion_info invif = minv_vector_bicgstab_l(prop, src, cv_size, max_iter, tol, bicgstab_l, apply_stencil_2D_M, (void*)wilson, &verb);
         if (!invif.success) unconverged++;
         vector<double>& p = spin ? pion_down : pion_up;
-        qmg::ok(qmg_norm2sq_cv_timeslice(prop, x_len, y_len, dof, 0, p.data(), qmg::current_stream()), "qmg_norm2sq_cv_timeslice");
+        norm2sq_cv_timeslice(p.data(), prop, lat);   // reductions/reductions.h:24-41
         for (int j = 1; j < y_len / 2; j++) { const double tmp = 0.5 * (p[j] + p[y_len - j]); p[j] = p[y_len - j] = tmp; }   // fold
       }
       for (int j = 0; j < y_len; j++) {

@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
       zero_vector(prop, cv_size);
       inversion_info invif = minv_vector_bicgstab_l(prop, src, cv_size, max_iter, tol, bicgstab_l, apply_stencil_2D_M, (void*)staggered, &verb);
       if (!invif.success) unconverged++;
-      qmg::ok(qmg_norm2sq_cv_timeslice(prop, x_len, y_len, dof, 0, pion_tmp.data(), qmg::current_stream()), "qmg_norm2sq_cv_timeslice");
+      norm2sq_cv_timeslice(pion_tmp.data(), prop, lat);   // reductions/reductions.h:24-41
       for (int j = 1; j < y_len / 2; j++) { const double tmp = 0.5 * (pion_tmp[j] + pion_tmp[y_len - j]); pion_tmp[j] = pion_tmp[y_len - j] = tmp; }   // fold
       for (int j = 0; j < y_len; j++) { pion[j] += pion_tmp[j]; pion_sq[j] += pion_tmp[j] * pion_tmp[j]; }
       count++;

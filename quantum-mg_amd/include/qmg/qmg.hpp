@@ -12,4 +12,5 @@
 #include "multigrid.hpp"
 #include "batch.hpp"
 #include "u1.hpp"
+#include "reductions.hpp"
 #endif

@@ -163,6 +163,13 @@ def build_rbjacobi(desc):
     return cinv, rclover, rhopping
 
 
+def build_rbj_dagger(cinv, rclover, rhopping, Lx, Ly, nc):
+    """stencil_2d.h:1989-2060: conj-transpose of cinv and of the identity clover, dagger of the right-block-Jacobi hopping."""
+    dcinv, dcl, dho = np.zeros_like(cinv), np.zeros_like(rclover), np.zeros_like(rhopping)
+    assert lib().qo_build_rbj_dagger(_p(dcinv), _p(dcl), _p(dho), _p(cinv), _p(rclover), _p(rhopping), Lx, Ly, nc) == 0
+    return dcinv, dcl, dho
+
+
 def norm2sq(x):
     return lib().qo_norm2sq(_p(x), C.c_long(x.size))
 
@@ -185,6 +192,19 @@ def norm2sq_cv_timeslice(cv, Lx, Ly, nc):
     s = np.zeros(Ly)
     lib().qo_norm2sq_cv_timeslice(_p(s), _p(cv), Lx, Ly, nc)
     return s
+
+
+def redot_cv_timeslice(a, b, Lx, Ly, nc):
+    s = np.zeros(Ly)
+    lib().qo_redot_cv_timeslice(_p(s), _p(a), _p(b), Lx, Ly, nc)
+    return s
+
+
+def gaussian_wall_source(Lx, Ly, nc, timeslice, color, seed, deviation=1.0, mean=0.0):
+    """None for an out-of-range timeslice / color (the reference prints an error and returns)."""
+    cv = cvec(Lx * Ly * nc)
+    rc = lib().qo_gaussian_wall_source(_p(cv), Lx, Ly, nc, timeslice, color, C.c_ulonglong(seed), C.c_double(deviation), C.c_double(mean))
+    return cv if rc == 0 else None
 
 
 def dot_cv_timeslice(a, b, Lx, Ly, nc):

@@ -350,6 +350,56 @@ def test_dagger_and_rbjacobi_builds(Lx, Ly, nc):
     assert abs(a - b) / abs(a) < 1e-12
 
 
+@pytest.mark.parametrize("Lx,Ly,nc", [(32, 32, 2), (12, 8, 3), (8, 8, 8)])
+def test_rbj_dagger_build_and_normal_operators(Lx, Ly, nc):
+    """a11 (stencil_2d.h:1989-2060, 2282-2411): the dagger of the right-block-Jacobi stencil -- conj-transposed cinv and (identity)
+    clover, hopping daggered with the neighbour shift -- against the oracle's restatement, bit for bit (pure data movement); then the two
+    normal operators the CGNE / CGNR smoothers apply, M_rbj^dag M_rbj (MDM, :2282-2299) and M_rbj M_rbj^dag (MMD, :2354-2371), as the
+    facade launches them (identity clover as a unit shift, hops from the built arrays) against the oracle applying the stored matrices
+    pass by pass, and <y, M_rbj x> = <M_rbj^dag y, x> (n21)."""
+    vol = Lx * Ly
+    clover = cs.gaussian_cvec(vol * nc * nc, 11) + 4.0 * np.tile(np.eye(nc).reshape(-1), vol)
+    hopping = cs.gaussian_cvec(4 * vol * nc * nc, 12)
+    shifts = (0.2 + 0.1j, 0.03, 0.05 if nc % 2 == 0 else 0.0)
+    cinv, rclover, rhopping = ol.build_rbjacobi(ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts))
+    want_cinv, want_cl, want_ho = ol.build_rbj_dagger(cinv, rclover, rhopping, Lx, Ly, nc)
+    # device: the same two entry points Stencil2D::build_rbj_dagger_stencil calls
+    g_cinv, g_rcl, g_rho = D(cinv), D(rclover), D(rhopping)
+    d_cinv, d_cl, d_ho = qmg.DeviceArray(cinv.size), qmg.DeviceArray(rclover.size), qmg.DeviceArray(rhopping.size)
+    qmg.build_dagger(d_cl, d_ho, g_rcl, g_rho, Lx, Ly, nc)
+    qmg.cmat_conjtrans(d_cinv, g_cinv, vol, nc)
+    assert np.array_equal(d_cinv.to_host(), want_cinv)
+    assert np.array_equal(d_cl.to_host(), want_cl)
+    assert np.array_equal(d_ho.to_host(), want_ho)
+    # normal operators: oracle applies clover (= identity matrices) + hopping of each stored stencil; device: unit shift + hops
+    n = vol * nc
+    x, y = cs.gaussian_cvec(n, 13), cs.gaussian_cvec(n, 14)
+    o_rbj = ol.make_desc(Lx, Ly, nc, rclover, rhopping, 0.0)
+    o_dag = ol.make_desc(Lx, Ly, nc, want_cl, want_ho, 0.0)
+    g_rbj = qmg.make_desc(Lx, Ly, nc, None, g_rho, 1.0)
+    g_dag = qmg.make_desc(Lx, Ly, nc, None, d_ho, 1.0)
+    pieces = qmg.P_HOPPING | qmg.P_SHIFT | qmg.P_ZERO
+    dx, t, u = D(x), qmg.DeviceArray(n), qmg.DeviceArray(n)
+    qmg.stencil_apply(g_rbj, t, dx, pieces); qmg.stencil_apply(g_dag, u, t, pieces)          # MDM
+    want = ol.stencil_apply(o_dag, ol.stencil_apply(o_rbj, x))
+    assert cs.rel_l2(u.to_host(), want) < TOL
+    qmg.stencil_apply(g_dag, t, dx, pieces); qmg.stencil_apply(g_rbj, u, t, pieces)          # MMD
+    want = ol.stencil_apply(o_rbj, ol.stencil_apply(o_dag, x))
+    assert cs.rel_l2(u.to_host(), want) < TOL
+    # reconstruct_M_rbjacobi_MMD (:2373-2392): x = cinv . M_rbj^dag y
+    qmg.stencil_apply(g_dag, t, D(y), pieces)
+    qmg.stencil_apply(qmg.make_desc(Lx, Ly, nc, g_cinv, None, 0.0), u, t, qmg.P_CLOVER | qmg.P_ZERO)
+    want = ol.stencil_apply(ol.make_desc(Lx, Ly, nc, cinv, None, 0.0), ol.stencil_apply(o_dag, y), ol.P_CLOVER | ol.P_ZERO)
+    assert cs.rel_l2(u.to_host(), want) < TOL
+    # adjointness (n21)
+    dy = D(y)
+    qmg.stencil_apply(g_rbj, t, dx, pieces)
+    a = qmg.dot(dy, t, n)
+    qmg.stencil_apply(g_dag, t, dy, pieces)
+    b = qmg.dot(t, dx, n)
+    assert abs(a - b) / abs(a) < 1e-12
+
+
 # ------------------------------------------------------------------ BLAS-1 and reductions (a21)
 def test_blas1_leaves():
     n = 100003

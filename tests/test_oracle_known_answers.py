@@ -218,3 +218,42 @@ def test_l128_fixture_is_past_critical_at_mass_minus_007(golden_dir):
     real_ev = np.sort(ev[np.abs(ev.imag) < 1e-9].real)
     assert real_ev[0] < 0.0 and abs(real_ev[0] + 2.5315e-4) < 2e-6, real_ev      # past critical
     assert real_ev[1] > 0.0                                                      # indefinite
+
+
+def test_n21_rbj_dagger_identity_on_the_oracle(golden_dir):
+    """a11 (stencil_2d.h:1989-2060): the oracle's rbj-dagger stencil is the adjoint of its right-block-Jacobi stencil,
+    <y, M_rbj x> = <M_rbj^dag y, x> (what n21 checks before its CGNE / CGNR solves), cinv^dag is the conj-transpose per site,
+    and the dagger of the identity clover is the identity."""
+    L = 32
+    ph, _ = _fixture_links(golden_dir, L)
+    clover, hopping = ol.wilson_fill(ol.phases_to_gauge_u1(ph, L, L), L, L)
+    d = ol.make_desc(L, L, 2, clover, hopping, shift=-0.07 + 0.02j)
+    cinv, rclover, rhopping = ol.build_rbjacobi(d)
+    dcinv, dcl, dho = ol.build_rbj_dagger(cinv, rclover, rhopping, L, L, 2)
+    assert np.array_equal(dcl, rclover)                                                   # identity blocks
+    assert np.array_equal(dcinv.reshape(-1, 2, 2), np.conj(cinv.reshape(-1, 2, 2).transpose(0, 2, 1)))
+    x, y = cs.gaussian_cvec(L * L * 2, 21), cs.gaussian_cvec(L * L * 2, 22)
+    a = np.vdot(y, ol.stencil_apply(ol.make_desc(L, L, 2, rclover, rhopping), x))
+    b = np.vdot(ol.stencil_apply(ol.make_desc(L, L, 2, dcl, dho), y), x)
+    assert abs(a - b) / abs(a) < 1e-12
+
+
+def test_redot_timeslice_and_wall_source():
+    """reductions/reductions.h:47-66 and :90-162 on the oracle: redot = Re(dot) per timeslice against a coordinate-space sum; the
+    wall source is real, lives on ONE timeslice and ONE component, is zero elsewhere, has the requested mean / deviation, and an
+    out-of-range timeslice or colour is refused."""
+    L, nc = 16, 2
+    a, b = cs.gaussian_cvec(L * L * nc, 3), cs.gaussian_cvec(L * L * nc, 4)
+    ga, gb = cs.eo_to_grid(a, L, L, nc), cs.eo_to_grid(b, L, L, nc)
+    assert np.allclose(ol.redot_cv_timeslice(a, b, L, L, nc), (np.conj(ga) * gb).sum(axis=(0, 2)).real, rtol=1e-13)
+    assert np.allclose(ol.redot_cv_timeslice(a, b, L, L, nc), ol.dot_cv_timeslice(a, b, L, L, nc).real, rtol=1e-13)
+    Lx, Ly = 64, 32
+    w = ol.gaussian_wall_source(Lx, Ly, nc, 5, 1, 1337, deviation=2.0, mean=0.5)
+    g = cs.eo_to_grid(w, Lx, Ly, nc)                  # [x, y, c]
+    assert not g.imag.any()
+    mask = np.zeros(g.shape, dtype=bool)
+    mask[:, 5, 1] = True
+    assert not g[~mask].any() and np.all(g[mask] != 0)
+    vals = np.concatenate([cs.eo_to_grid(ol.gaussian_wall_source(Lx, Ly, nc, t, 1, 7 + t, deviation=2.0, mean=0.5), Lx, Ly, nc)[:, t, 1].real for t in range(Ly)])
+    assert abs(vals.mean() - 0.5) < 0.15 and abs(vals.std() - 2.0) < 0.15          # 2048 draws
+    assert ol.gaussian_wall_source(Lx, Ly, nc, Ly, 0, 1) is None and ol.gaussian_wall_source(Lx, Ly, nc, 0, nc, 1) is None

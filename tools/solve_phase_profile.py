@@ -47,7 +47,14 @@ def summarise(rs):
         per[key][0] += 1
         per[key][1] += e - s
     top = sorted(per.items(), key=lambda kv: -kv[1][1])
-    return {"wall_ms": wall / 1e6, "gpu_busy_ms": busy / 1e6, "idle_frac": 1.0 - busy / wall, "launches": len(rs),
+    # where the GPU idles: gaps grouped by the kernel that PRECEDES them (after a reduction's final kernel = a host round trip)
+    gaps = defaultdict(lambda: [0, 0])
+    for a, b in zip(rs, rs[1:]):
+        key = a[2].split("(")[0].replace("void qmg::", "").replace("qmg::", "")
+        gaps[key][0] += 1
+        gaps[key][1] += max(0, b[0] - a[1])
+    gtop = sorted(gaps.items(), key=lambda kv: -kv[1][1])
+    return {"gaps_after": [{"kernel": k, "gaps": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3} for k, v in gtop[:16]],"wall_ms": wall / 1e6, "gpu_busy_ms": busy / 1e6, "idle_frac": 1.0 - busy / wall, "launches": len(rs),
             "avg_gap_us": (wall - busy) / 1e3 / max(1, len(rs) - 1),
             "kernels": [{"kernel": k, "calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3, "pct_of_wall": 100.0 * v[1] / wall} for k, v in top[:24]]}
 
