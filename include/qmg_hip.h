@@ -283,6 +283,42 @@ int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n
                        double* out_host, void* stream);
 int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
                          double* out_host, void* stream);
+/* The K-cycle's smoother, MR(omega) of quantum-linalg's minv_vector_minres (call sites multigrid/stateful_multigrid.h:851-860, 1037-1046),
+ * with EVERY SCALAR ON THE DEVICE: the smoothers run a fixed number of iterations (their tolerance, 1e-15, is never met), so no host
+ * decision depends on <p,r> / <p,p> and the host round trip of each iteration can go.  Per step, after p = A r:
+ *   qmg_batch_mr_dots_t     <p_k,r_k>, <p_k,p_k> of the active systems into the calling thread's device slot (one pass over p and r;
+ *                           same two-stage deterministic reduction, hence the same bits, as qmg_batch_multidot_t; summed over ranks
+ *                           under distributed reductions).  A stencil apply with the MR epilogue (qmg_stencil_apply_epi_t) fills the
+ *                           same slot from the apply's own pass instead.
+ *   qmg_batch_mr_update_t   alpha_k = omega <p_k,r_k> / <p_k,p_k> formed on the device (0 when <p_k,p_k> == 0);
+ *                           x (+)= alpha r_in ;  r_out = r_in - alpha p.  x_set: x = alpha r_in (first step from x0 = 0);
+ *                           r_out == NULL: residual not wanted; r_out may alias r_in.
+ *   qmg_batch_mr_read_dots  the slot (4 doubles per system: Re<p,r>, Im<p,r>, <p,p>, -) on the host; synchronises (tests). */
+/* A stencil apply with an EPILOGUE on every finished site value of the processed parities (kernels B / B32: any nc but 1, 2, 4; one
+ * system per launch), instead of separate BLAS-1 passes over the result:
+ *   out = other_scale * other + acc_scale * acc   (other == NULL: out = acc_scale * acc)  -- the residual b - A x of stateful_multigrid.h:863-866 /
+ *         1023-1029, the Schur complement's r_e - D'_eo t of stencil_2d.h:1894-1907;
+ *   dotv != NULL: <out, dotv> and <out, out> go to the calling thread's MR slot (qmg_batch_mr_update_t consumes them) -- minv_vector_minres's
+ *         <p,r> and <p,p> with p = out, r = dotv, from the apply's own pass.
+ * other / dotv: vectors with lhs's layout, precision and stride (element `system * vec_stride` onwards is used, like lhs and rhs).  Needs
+ * overwrite semantics (QMG_P_ZERO on the processed parities); lhs must differ from rhs, other and dotv.  mat32: the matrices are complex<float>
+ * (qmg_stencil_apply_mat32's storage) with dtype's vectors.  QMG_ERR_UNSUPPORTED: this operator is not served with an epilogue (nc = 1, 2, 4:
+ * see qmg_wilson_apply_direct_epi) -- run the separate passes. */
+typedef struct { const void* other; double other_scale, acc_scale; const void* dotv; } qmg_apply_epilogue;
+int qmg_stencil_apply_epi_t(int dtype, int mat32, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, size_t vec_stride, int system,
+                            const qmg_apply_epilogue* epi, void* stream);
+/* qmg_wilson_apply_direct / qmg_wilson_hops_direct with the same epilogue (kernel W, nc = 2, both storage precisions): ONE system per launch
+ * (exactly one bit of `mask`), whole lattice or slab with all its rows (rows = 0). */
+int qmg_wilson_apply_direct_epi(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
+                                const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask,
+                                const qmg_apply_epilogue* epi, void* stream);
+int qmg_wilson_hops_direct_epi(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, double hop_scale, void* lhs,
+                               const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride,
+                               unsigned mask, const qmg_apply_epilogue* epi, void* stream);
+int qmg_batch_mr_dots_t(int dtype, const void* r, const void* p, size_t n, int nrhs, size_t stride, unsigned mask, void* stream);
+int qmg_batch_mr_update_t(int dtype, double omega, void* x, const void* r_in, void* r_out, const void* p, int x_set, size_t n, int nrhs,
+                          size_t stride, unsigned mask, void* stream);
+int qmg_batch_mr_read_dots(double* out_host, int nrhs, void* stream);
 int qmg_prolong_batch_t(int dtype, const void* nullvecs, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc,
                         int cLx, int cLy, int cnc, int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream);
 int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,

@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_norm2",
     "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_staggered_fill_slab", "qmg_laplace_fill_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
+    "qmg_stencil_apply_epi_t", "qmg_wilson_apply_direct_epi", "qmg_wilson_hops_direct_epi", "qmg_batch_mr_dots_t", "qmg_batch_mr_update_t", "qmg_batch_mr_read_dots",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
 ]
 
@@ -381,6 +382,48 @@ def coarse_build(cclover, chopping, fdesc, nullvecs, cdims, restrict_vecs=None):
 def coarse_build_slab(cclover, chopping, fdesc, nullvecs, cdims, halo_lo, halo_hi, halo_stride, restrict_vecs=None):
     check(lib().qmg_coarse_build_slab(_vp(cclover), _vp(chopping), C.byref(fdesc), _vp(nullvecs), _vp(restrict_vecs), *cdims, _vp(halo_lo), _vp(halo_hi),
                                       C.c_size_t(halo_stride), None), "qmg_coarse_build_slab")
+
+
+class ApplyEpilogue(C.Structure):
+    _fields_ = [("other", C.c_void_p), ("other_scale", C.c_double), ("acc_scale", C.c_double), ("dotv", C.c_void_p)]
+
+
+def make_epilogue(other=None, other_scale=1.0, acc_scale=-1.0, dotv=None):
+    e = ApplyEpilogue()
+    e.other = None if other is None else (other.ptr if isinstance(other, DeviceArray) else int(other))
+    e.other_scale, e.acc_scale = other_scale, acc_scale
+    e.dotv = None if dotv is None else (dotv.ptr if isinstance(dotv, DeviceArray) else int(dotv))
+    return e
+
+
+def stencil_apply_epi(dtype, mat32, desc, lhs, rhs, pieces, epi, vec_stride=0, system=0):
+    """status (0 = done, 3 = this operator is not served with an epilogue) of qmg_stencil_apply_epi_t"""
+    return lib().qmg_stencil_apply_epi_t(dtype, int(mat32), C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), C.c_size_t(vec_stride), system, C.byref(epi), None)
+
+
+def wilson_apply_direct_epi(dtype, desc, gauge, lhs, rhs, pieces, epi, nrhs=1, vec_stride=0, mask=1, wilson_coeff=1.0):
+    return lib().qmg_wilson_apply_direct_epi(dtype, C.byref(desc), _vp(gauge), desc.Ly, 0, C.c_double(wilson_coeff), _vp(lhs), _vp(rhs), None, None, C.c_uint(pieces), nrhs,
+                                             C.c_size_t(vec_stride), C.c_size_t(0), C.c_uint(mask), C.byref(epi), None)
+
+
+def wilson_hops_direct_epi(dtype, desc, gauge, hop_scale, lhs, rhs, pieces, epi, nrhs=1, vec_stride=0, mask=1, wilson_coeff=1.0):
+    return lib().qmg_wilson_hops_direct_epi(dtype, C.byref(desc), _vp(gauge), desc.Ly, 0, C.c_double(wilson_coeff), C.c_double(hop_scale), _vp(lhs), _vp(rhs), None, None,
+                                            C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_size_t(0), C.c_uint(mask), C.byref(epi), None)
+
+
+def batch_mr_dots(dtype, r, p, n, nrhs, stride, mask):
+    check(lib().qmg_batch_mr_dots_t(dtype, _vp(r), _vp(p), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None), "qmg_batch_mr_dots_t")
+
+
+def batch_mr_update(dtype, omega, x, r_in, r_out, p, x_set, n, nrhs, stride, mask):
+    check(lib().qmg_batch_mr_update_t(dtype, C.c_double(omega), _vp(x), _vp(r_in), _vp(r_out), _vp(p), int(x_set), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None),
+          "qmg_batch_mr_update_t")
+
+
+def batch_mr_read_dots(nrhs):
+    out = (C.c_double * (4 * nrhs))()
+    check(lib().qmg_batch_mr_read_dots(out, nrhs, None), "qmg_batch_mr_read_dots")
+    return np.array(out).reshape(nrhs, 4)
 
 
 def gaussian_slab(x, Lx, Ly_global, y0, Ly_local, nc, seed):

@@ -195,10 +195,71 @@ __global__ __launch_bounds__(BLOCK) void k_breduce_final(const double* __restric
   }
 }
 
+// MR(omega) update with the step length formed ON THE DEVICE from the dots the previous launches left in `dots` ([system][4]:
+// Re<p,r>, Im<p,r>, <p,p>): alpha = omega conj(<p,r>)... written as krylov.hpp writes it, alpha = omega * <r,p>^* / <p,p> with
+// <p,r> = conj(<r,p>); 0 when <p,p> == 0 (the host loop's breakdown `break`: the system is left as it is).
+//   x (+)= alpha r_in ;  r_out = r_in - alpha p   (r_out == nullptr: not wanted; r_out may alias r_in)
+// XSET: x = alpha r_in (the first step of a smoother that starts from x0 = 0: no zero-fill, no read of x).
+template <typename T, int W, bool XSET>
+__global__ __launch_bounds__(BLOCK) void k_bmr_update(void* __restrict__ x_, const void* __restrict__ rin_, void* rout_, const void* __restrict__ p_,
+                                                      const double* __restrict__ dots, double omega, const BatchIdx bi, long n, long stride) {
+  typedef typename CStore<T>::type ct;
+  const int k = bi.id[blockIdx.y];
+  const long off = (long)k * stride;
+  ct* x = reinterpret_cast<ct*>(x_) + off;
+  const ct* rin = reinterpret_cast<const ct*>(rin_) + off;
+  ct* rout = rout_ ? reinterpret_cast<ct*>(rout_) + off : nullptr;
+  const ct* p = reinterpret_cast<const ct*>(p_) + off;
+  const double prx = dots[4 * k], pry = dots[4 * k + 1], pp = dots[4 * k + 2];   // <p,r> = (prx, pry)
+  // alpha = omega * <p,r> / <p,p> in the host loop's operation order: (omega * pr) / pp
+  const cplx alpha = (pp == 0.0) ? cmake(0.0, 0.0) : cmake((omega * prx) / pp, (omega * pry) / pp);
+  const cplx malpha = cmake(-alpha.x, -alpha.y);
+  const long np = n / W;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
+    cplx xv[W], rv[W], pv[W];
+    ldc_pack<T, W>(rin, i, rv);
+    if (!XSET) ldc_pack<T, W>(x, i, xv);
+#pragma unroll
+    for (int w = 0; w < W; w++) { if (XSET) xv[w] = cmul(alpha, rv[w]); else cmac(xv[w], alpha, rv[w]); }
+    stc_pack<T, W>(x, i, xv);
+    if (rout) {
+      ldb<T, W>(p, i, pv, bi.nt);
+#pragma unroll
+      for (int w = 0; w < W; w++) cmac(rv[w], malpha, pv[w]);
+      stc_pack<T, W>(rout, i, rv);
+    }
+  }
+}
+
+// stage 2 of the MR dots: out[system][4] <- {sum of partial q = 0, 1 (<r,p>: conjugated into <p,r>), q = 3 (<p,p>)}; one block per system
+__global__ __launch_bounds__(BLOCK) void k_bmr_final(const double* __restrict__ partials, int nparts, const BatchIdx bi, double* __restrict__ out) {
+  __shared__ double sm[3][BLOCK / WAVE];
+  const int s = blockIdx.x;
+  const double* p = partials + (long)s * nparts * 4;   // multidot of {r, p} against p: [part][4] = Re<r,p>, Im<r,p>, <p,p>, 0
+  double t[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += BLOCK) { t[0] += p[(long)i * 4]; t[1] += p[(long)i * 4 + 1]; t[2] += p[(long)i * 4 + 2]; }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const double w = wave_sum(t[q]);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sm[q][threadIdx.x / WAVE] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double r = sm[threadIdx.x][0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / WAVE; w++) r += sm[threadIdx.x][w];
+    // <p,r> = conj(<r,p>): the imaginary part changes sign (krylov.hpp: pr = conj(d2[0]))
+    out[4 * bi.id[s] + threadIdx.x] = (threadIdx.x == 1) ? -r : r;
+  }
+}
+
 struct BatchWorkspace {
   double* partials = nullptr;   // BATCH_MAX * BRED_BLOCKS * 2 * BDOT_MAX doubles (8 MiB)
   double* pinned = nullptr;     // host-pinned, device-visible results: BATCH_MAX * 2 * BDOT_MAX doubles
   double* result = nullptr;     // the same in HBM: where the results go when they are summed over ranks first
+  double* mr = nullptr;         // device-resident scalars of the MR smoother: [system][4] = Re<p,r>, Im<p,r>, <p,p>, - (qmg_batch_mr_*)
+  double* epi_part = nullptr;   // partials of an apply's MR epilogue ([system slot][wavefront][4]), grown on demand
+  size_t epi_cap = 0;
   int device = -1;
 };
 static thread_local BatchWorkspace g_bws;
@@ -211,6 +272,8 @@ static int get_bws(BatchWorkspace** out) {
     QMG_HIP_CHECK(hipHostMalloc((void**)&g_bws.pinned, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX, hipHostMallocDefault));
     QMG_HIP_CHECK(hipMalloc((void**)&g_bws.result, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
     QMG_HIP_CHECK(hipMemset(g_bws.result, 0, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
+    QMG_HIP_CHECK(hipMalloc((void**)&g_bws.mr, sizeof(double) * BATCH_MAX * 4));
+    QMG_HIP_CHECK(hipMemset(g_bws.mr, 0, sizeof(double) * BATCH_MAX * 4));
     g_bws.device = dev;
   }
   *out = &g_bws;
@@ -221,7 +284,22 @@ void release_batch_workspace() {   // qmg_shutdown (qmg_runtime.hip)
   if (g_bws.partials) hipFree(g_bws.partials);
   if (g_bws.result) hipFree(g_bws.result);
   if (g_bws.pinned) hipHostFree(g_bws.pinned);
+  if (g_bws.mr) hipFree(g_bws.mr);
+  if (g_bws.epi_part) hipFree(g_bws.epi_part);
   g_bws = BatchWorkspace();
+}
+
+double* mr_epilogue_begin(int nsys, long npart) {
+  BatchWorkspace* ws;
+  if (get_bws(&ws) != QMG_SUCCESS) return nullptr;
+  const size_t need = (size_t)nsys * (size_t)npart * 4;
+  if (ws->epi_cap < need) {
+    if (ws->epi_part) { if (hipFree(ws->epi_part) != hipSuccess) return nullptr; }   // (synchronises: nothing still writes the old buffer)
+    ws->epi_part = nullptr; ws->epi_cap = 0;
+    if (hipMalloc((void**)&ws->epi_part, sizeof(double) * need) != hipSuccess) return nullptr;
+    ws->epi_cap = need;
+  }
+  return ws->epi_part;
 }
 
 static unsigned bred_grid(long n) {
@@ -229,6 +307,22 @@ static unsigned bred_grid(long n) {
   if (b > BRED_BLOCKS) b = BRED_BLOCKS;
   if (b < 1) b = 1;
   return (unsigned)b;
+}
+
+int mr_epilogue_finish(const unsigned char* ids, int n, long npart, hipStream_t st) {
+  BatchWorkspace* ws;
+  int rc = get_bws(&ws);
+  if (rc) return rc;
+  if (n < 1 || n > BATCH_MAX || !ws->epi_part) return QMG_ERR_INVALID;
+  BatchIdx bi;
+  bi.n = n; bi.nt = 0;
+  for (int k = 0; k < BATCH_MAX; k++) bi.id[k] = (k < n) ? ids[k] : (unsigned char)0;
+  const bool dist = dist_reductions_on();
+  if (dist) QMG_HIP_CHECK(hipMemsetAsync(ws->mr, 0, sizeof(double) * 4 * BATCH_MAX, st));   // inactive slots must not accumulate over the ranks call after call
+  k_bmr_final<<<(unsigned)n, BLOCK, 0, st>>>(ws->epi_part, (int)npart, bi, ws->mr);
+  QMG_LAUNCH_CHECK();
+  if (dist) { rc = dist_allreduce(ws->mr, 4 * BATCH_MAX, false, st); if (rc) return rc; }
+  return QMG_SUCCESS;
 }
 
 // which access width the arrays of a call allow: 2 complex<float> per 16-byte access needs 16-byte aligned bases, even
@@ -408,6 +502,73 @@ int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y
 }
 int qmg_batch_multidot(const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask, double* out_host, void* stream) {
   return qmg_batch_multidot_t(QMG_C64, xs, nj, y, n, nrhs, stride, mask, out_host, stream);
+}
+
+// ---- MR(omega) with every scalar on the device (the smoothers of the K-cycle: fixed iteration counts, no host decision) ----
+// qmg_batch_mr_dots_t: <p_k, r_k> and <p_k, p_k> of the active systems into the calling thread's device slot (one pass over p and r,
+// the same two-stage deterministic reduction as qmg_batch_multidot of {r, p} against p, summed over ranks under distributed
+// reductions).  Nothing comes back to the host; nothing synchronises.
+int qmg_batch_mr_dots_t(int dtype, const void* r, const void* p, size_t n, int nrhs, size_t stride, unsigned mask, void* stream) {
+  if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || !r || !p) return QMG_ERR_INVALID;
+  BatchIdx bi = expand_mask(mask, nrhs);
+  if (bi.n == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
+  BatchWorkspace* ws;
+  int rc = get_bws(&ws);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  BatchPtrs ptr;
+  for (int j = 0; j < BDOT_MAX; j++) ptr.x[j] = nullptr;
+  ptr.x[0] = r; ptr.x[1] = p;
+  int W = pack_width(dtype, n, stride, nrhs, {r, p});
+  const unsigned g = bred_grid((long)(n / W));
+  dim3 grid(g, (unsigned)bi.n);
+#define QMG_K(T, WW) k_bmultidot<2, T, WW><<<grid, BLOCK, 0, st>>>(ptr, 0, p, (long)n, (long)stride, bi, ws->partials, 2)
+  QMG_DISPATCH_TW(dtype, W, QMG_K);
+#undef QMG_K
+  QMG_LAUNCH_CHECK();
+  const bool dist = dist_reductions_on();
+  if (dist) QMG_HIP_CHECK(hipMemsetAsync(ws->mr, 0, sizeof(double) * 4 * BATCH_MAX, st));   // inactive slots must not accumulate over the ranks call after call
+  k_bmr_final<<<(unsigned)bi.n, BLOCK, 0, st>>>(ws->partials, (int)g, bi, ws->mr);
+  QMG_LAUNCH_CHECK();
+  if (dist) { rc = dist_allreduce(ws->mr, 4 * BATCH_MAX, false, st); if (rc) return rc; }
+  return QMG_SUCCESS;
+}
+
+// qmg_batch_mr_update_t: with alpha_k = omega <p_k, r_k> / <p_k, p_k> formed on the device from the slot qmg_batch_mr_dots_t (or a stencil
+// apply with the MR epilogue) filled on this stream:   x (+)= alpha r_in ;  r_out = r_in - alpha p.
+//   x_set != 0: x = alpha r_in (first step from x0 = 0: x is written, never read);  r_out == NULL: the new residual is not wanted;
+//   r_out may alias r_in.  <p,p> == 0 leaves the system unchanged (alpha = 0), as the host loop's breakdown exit does.
+int qmg_batch_mr_update_t(int dtype, double omega, void* x, const void* r_in, void* r_out, const void* p, int x_set, size_t n, int nrhs, size_t stride,
+                          unsigned mask, void* stream) {
+  if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || !x || !r_in || (r_out && !p)) return QMG_ERR_INVALID;
+  BatchIdx bi = expand_mask(mask, nrhs);
+  if (bi.n == 0 || n == 0) return QMG_SUCCESS;
+  bi.nt = batch_nt(bi, n, dtype);
+  BatchWorkspace* ws;
+  int rc = get_bws(&ws);
+  if (rc) return rc;
+  const int W = pack_width(dtype, n, stride, nrhs, {x, r_in, r_out, p});
+  dim3 grid(grid_1d(n / W), (unsigned)bi.n);
+  hipStream_t st = as_stream(stream);
+#define QMG_K(T, WW)                                                                                                               \
+  if (x_set) k_bmr_update<T, WW, true><<<grid, BLOCK, 0, st>>>(x, r_in, r_out, p, ws->mr, omega, bi, (long)n, (long)stride);        \
+  else k_bmr_update<T, WW, false><<<grid, BLOCK, 0, st>>>(x, r_in, r_out, p, ws->mr, omega, bi, (long)n, (long)stride)
+  QMG_DISPATCH_TW(dtype, W, QMG_K);
+#undef QMG_K
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+// the slot itself (4 doubles per system: Re<p,r>, Im<p,r>, <p,p>, -) copied to the host: tests and diagnostics; synchronises
+int qmg_batch_mr_read_dots(double* out_host, int nrhs, void* stream) {
+  if (!out_host || nrhs < 1 || nrhs > BATCH_MAX) return QMG_ERR_INVALID;
+  BatchWorkspace* ws;
+  int rc = get_bws(&ws);
+  if (rc) return rc;
+  QMG_HIP_CHECK(hipMemcpyAsync(out_host, ws->mr, sizeof(double) * 4 * nrhs, hipMemcpyDeviceToHost, as_stream(stream)));
+  QMG_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return QMG_SUCCESS;
 }
 
 }  // extern "C"

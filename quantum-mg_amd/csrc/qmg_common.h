@@ -192,6 +192,27 @@ inline BatchIdx expand_mask(unsigned mask, int nrhs) {
   return b;
 }
 
+// ---------------- apply epilogue (qmg_stencil_apply_epi_t, qmg_wilson_*_direct_epi): what a stencil kernel does with a finished site value ----------------
+//   out = other_scale * other + acc_scale * acc      (other == nullptr: out = acc)      -- residuals b - A x, the Schur complement's r_e - D_eo t
+//   dotv != nullptr: per-wavefront partial sums of conj(dotv) out (re, im) and |out|^2 go to `part`, [system slot][npart][4]   -- MR's <p,r>, <p,p>
+// `other` and `dotv` are vectors with the layout, precision, stride and system numbering of lhs; only the parities the launch processes are
+// touched.  Needs overwrite semantics (QMG_P_ZERO on the processed parities).  The dots are taken of the value AS STORED (rounded to the
+// storage precision first), so they are the dots a separate pass over the stored vector would form.
+struct Epilogue {
+  const void* other;
+  const void* dotv;
+  double other_scale, acc_scale;
+  double* part;
+  long npart;        // partial slots per system (wavefronts of the launch)
+  int on;
+};
+inline Epilogue no_epilogue() { Epilogue e; e.other = nullptr; e.dotv = nullptr; e.other_scale = 0.0; e.acc_scale = 1.0; e.part = nullptr; e.npart = 0; e.on = 0; return e; }
+// qmg_batch.hip: the calling thread's MR slot.  begin: a partial buffer of nsys * npart * 4 doubles (grown on demand; nullptr on failure);
+// finish: second stage -- the partials of the n systems `ids` summed in index order into the slot (conjugated to <p,r>), summed over ranks
+// under distributed reductions.
+double* mr_epilogue_begin(int nsys, long npart);
+int mr_epilogue_finish(const unsigned char* ids, int n, long npart, hipStream_t st);
+
 extern int g_malloc_poison;   // qmg_runtime.hip; "malloc_poison"
 // qmg_shutdown: the calling thread's reduction / norm workspaces (qmg_blas.hip, qmg_batch.hip, qmg_stencil.hip)
 void release_blas_workspace();

@@ -57,6 +57,8 @@ struct StencilArgs {
   long halo_stride;
   // fused |lhs_k|^2 (kernel A2 with NORM, qmg_stencil_apply_norm2): one partial per (row group, block, wavefront, system)
   double* norm_part;
+  // apply epilogue (kernels B / B32, one system per launch): out = other_scale other + acc_scale acc, MR dots of out (qmg_common.h)
+  Epilogue epi;
 #ifdef QMG_DIAGNOSTICS
   int ablate;        // tools-only build (make DIAG=1; tools/variants.py): 1 = neighbours := own site, 2 = no store, 4 = no rhs loads
 #endif
@@ -75,6 +77,34 @@ __device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return
 // vector element i of a complex<double> (V32 = false) or complex<float> (V32 = true) array, in fp64 registers
 template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i) { return V32 ? ldc<float>(base, i) : ldc<double>(base, i); }
 template <bool V32> __device__ __forceinline__ void stv(void* base, long i, cplx v) { if (V32) stc<float>(base, i, v); else stc<double>(base, i, v); }
+
+// the epilogue of one output element (qmg_common.h: Epilogue): returns the value to store, accumulates the MR dots of the value AS STORED
+template <bool V32>
+__device__ __forceinline__ cplx epilogue_value(const Epilogue& e, long o, cplx t, double (&d)[3]) {
+  if (e.other) {
+    const cplx ov = ldv<V32>(e.other, o);
+    t = cmake(fma(e.other_scale, ov.x, e.acc_scale * t.x), fma(e.other_scale, ov.y, e.acc_scale * t.y));
+  } else if (e.acc_scale != 1.0) t = cmake(e.acc_scale * t.x, e.acc_scale * t.y);
+  if (e.dotv) {
+    const cplx sv = V32 ? cmake((double)(float)t.x, (double)(float)t.y) : t;
+    const cplx r = ldv<V32>(e.dotv, o);
+    d[0] = fma(r.x, sv.x, d[0]); d[0] = fma(r.y, sv.y, d[0]);      // conj(r) out
+    d[1] = fma(r.x, sv.y, d[1]); d[1] = fma(-r.y, sv.x, d[1]);
+    d[2] = fma(sv.x, sv.x, d[2]); d[2] = fma(sv.y, sv.y, d[2]);
+  }
+  return t;
+}
+// end of a ROW of a kernel with an epilogue: one partial per (row, block, wavefront), [slot][4] (system slot 0); every lane of the block calls it.
+// Per row, not per launch, so that the dot accumulators are not carried around the row loop (7 VGPRs and, for several tile shapes, a
+// wavefront of occupancy in the launches that have no epilogue at all).
+__device__ __forceinline__ void epilogue_store_partials(const Epilogue& e, double (&d)[3], int row) {
+  const double s0 = wave_sum(d[0]), s1 = wave_sum(d[1]), s2 = wave_sum(d[2]);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    const long w = ((long)row * gridDim.x + blockIdx.x) * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    double* p = e.part + w * 4;
+    p[0] = s0; p[1] = s1; p[2] = s2; p[3] = 0.0;
+  }
+}
 
 template <bool NT>
 __device__ __forceinline__ cplx ld(const cplx* p) {
@@ -494,7 +524,9 @@ constexpr int GEN_MAX_PER_THREAD = 12;   // register-staged matrix elements per 
 // KR = right-hand sides per pass: the matrix tile parked in LDS is used for KR vectors (KR accumulators per thread), so a
 // batch reads the matrices once per KR systems for ANY nc -- the vector-FMA counterpart of kernel C, and the better one
 // where the 16x16 MFMA tile would be mostly padding (nc = 8: 1024^2, 8 rhs 2.0 ms on the matrix cores).
-template <int PT, bool M32, int KR, bool V32>
+// EPI (KR = 1 only): the apply epilogue of qmg_common.h, a COMPILE-TIME switch -- as a run-time branch it cost every launch ~9 VGPRs and,
+// for several tile shapes, a wavefront of occupancy.
+template <int PT, bool M32, int KR, bool V32, bool EPI = false>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   cplx* mlds = reinterpret_cast<cplx*>(smem_raw);                    // [S*nc rows][rs]
@@ -517,6 +549,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
   const long nc2 = (long)nc * nc;
 
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue over this row (one system per launch)
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
     const int y = (a.par_count == 2) ? (row >> 1) : row;
     const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
@@ -669,10 +702,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
           const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
           if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
+          if (EPI) t = epilogue_value<V32>(a.epi, o, t, edots);
           stv<V32>(a.lhs, o, t);
         }
       }
     }
+    if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots, row);
   }
 }
 
@@ -680,7 +715,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 // loads carry two matrix elements, the staging registers and the LDS tile hold raw float pairs (half the registers, half
 // the LDS: twice the resident blocks), and an element is widened to fp64 only when it is multiplied.  PP = staged PAIRS per
 // thread.  Row stride nc + 2 floats-pairs: even (16-B aligned pair stores) and conflict-free for the 8-byte row reads.
-template <int PP, int KR, bool V32>
+template <int PP, int KR, bool V32, bool EPI = false>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int rs32 = nc + 2;
@@ -704,6 +739,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
   const long nc2 = (long)nc * nc;
 
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+    double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue over this row (one system per launch)
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
     const int y = (a.par_count == 2) ? (row >> 1) : row;
     const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
@@ -822,10 +858,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
           const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
           if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
+          if (EPI) t = epilogue_value<V32>(a.epi, o, t, edots);
           stv<V32>(a.lhs, o, t);
         }
       }
     }
+    if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots, row);
   }
 }
 
@@ -1263,7 +1301,21 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
 
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
                               const unsigned char* ridx, void* stream, int mat32 = 0, int vec32 = 0, const SlabHalo* slab = nullptr,
-                              double* norms_dev = nullptr);
+                              double* norms_dev = nullptr, const qmg_apply_epilogue* epi = nullptr);
+
+// One system with an epilogue on the finished site values (include/qmg_hip.h: qmg_apply_epilogue).  dtype QMG_C64: fp64 matrices and
+// vectors; mat32 != 0: complex<float> matrices (d->clover / d->hopping point to float pairs) with fp64 vectors; QMG_C32: both fp32.
+// QMG_ERR_UNSUPPORTED where the dispatch lands on a kernel without the epilogue (nc = 1, 2, 4; batches): the caller runs the
+// separate passes instead.
+extern "C" int qmg_stencil_apply_epi_t(int dtype, int mat32, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, size_t vec_stride, int system,
+                                       const qmg_apply_epilogue* epi, void* stream) {
+  if (!epi || (dtype != QMG_C64 && dtype != QMG_C32) || system < 0 || system > 15) return QMG_ERR_INVALID;
+  if (dtype == QMG_C32 && !mat32) return QMG_ERR_INVALID;
+  if (mat32 && d && (d->nc == 1 || d->nc == 2 || d->nc == 4)) return QMG_ERR_UNSUPPORTED;
+  unsigned char ridx[16];
+  for (int k = 0; k < 16; k++) ridx[k] = (unsigned char)system;
+  return stencil_apply_impl(d, lhs, rhs, pieces, 1, vec_stride, system ? ridx : nullptr, stream, mat32 ? 1 : 0, dtype == QMG_C32 ? 1 : 0, nullptr, nullptr, epi);
+}
 
 // partials of the fused norms (one buffer per host thread = per rank, grown on demand) and the default result slot
 struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; double* own = nullptr; int own_dev = -1; };
@@ -1356,8 +1408,20 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1, 1);
 }
 
+// the epilogue's dot partials: one slot per (row, block, wavefront) (system slot 0), summed by mr_epilogue_finish into the thread's MR slot
+#define QMG_EPI_BEGIN(GX, GY)                                                                   \
+  long epi_npart = 0;                                                                           \
+  if (a.epi.on && a.epi.dotv) {                                                                 \
+    epi_npart = (long)(GX) * (long)(GY) * (BLOCK / WAVE);                                       \
+    a.epi.part = mr_epilogue_begin(1, epi_npart);                                               \
+    a.epi.npart = epi_npart;                                                                    \
+    if (!a.epi.part) return QMG_ERR_HIP;                                                        \
+  }
+#define QMG_EPI_FINISH()                                                                        \
+  if (epi_npart) { const unsigned char id0 = a.ridx[0]; const int erc = mr_epilogue_finish(&id0, 1, epi_npart, st); if (erc) return erc; }
+
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
-                              const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab, double* norms_dev) {
+                              const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab, double* norms_dev, const qmg_apply_epilogue* epi) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
@@ -1372,7 +1436,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
   if (slab && mat32 != vec32) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2) or kernel B (any nc), matrices and vectors in ONE precision
-  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && !norms_dev && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
+  if (epi && (norms_dev || nrhs != 1)) return QMG_ERR_UNSUPPORTED;   // the epilogue is served for ONE system per launch, by kernels B / B32
+  if (nc == 2 && mat32 == vec32 && nrhs <= 16 && !norms_dev && !epi && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
     const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !slab && !(g_stencil_site & 4), slab);
     if (rc != SITE_DECLINED) return rc;
   }
@@ -1389,6 +1454,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.halo_hi = slab ? slab->hi : nullptr;
   a.halo_stride = slab ? slab->stride : 0;
   a.norm_part = nullptr;
+  a.epi = no_epilogue();
   for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
 #ifdef QMG_DIAGNOSTICS
   a.ablate = g_stencil_ablate;
@@ -1438,6 +1504,18 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     k_apply_norm_final<<<nrhs, BLOCK, 0, st>>>(ws.part, nparts, norms_dev);
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
+  }
+
+  if (epi) {
+    // out = other_scale other + acc_scale acc and the MR dots, in kernels B / B32 (any nc the generic kernels serve); the processed
+    // parities must be overwritten (an accumulate into lhs and an `other` term at once has no single meaning)
+    if (nc == 1 || nc == 2 || nc == 4) return QMG_ERR_UNSUPPORTED;   // kernels A / S / W: qmg_wilson_*_direct has its own epilogue, the rest falls back
+    if ((ev && !(pieces & QMG_P_ZERO_E)) || (od && !(pieces & QMG_P_ZERO_O))) return QMG_ERR_INVALID;
+    if (lhs == rhs || epi->other == lhs || epi->dotv == lhs) return QMG_ERR_INVALID;
+    a.epi.on = 1;
+    a.epi.other = epi->other; a.epi.other_scale = epi->other_scale; a.epi.acc_scale = epi->acc_scale;
+    a.epi.dotv = epi->dotv;
+    // partials: one per wavefront of the launch; the grid is fixed below (kernel B / B32: gx = ceil(hr / S), gy rows)
   }
 
   // fp32: the one-site-per-lane-group kernel is the faster one (4096^2 Wilson: 0.573 ms against 0.592 ms for the paired
@@ -1555,12 +1633,16 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       if (smem <= 64 * 1024) {
         const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
         dim3 grid(gx, gy), block(BLOCK);
+        QMG_EPI_BEGIN(gx, a.nrows)
 #define QMG_G32_CASE2(PP, KR) { if (a.vec32) k_stencil_gen32<PP, KR, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, KR, false><<<grid, block, smem, st>>>(a, nc, L); }
-#define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else { QMG_G32_CASE2(PP, 1) } } break;
+#define QMG_G32_EPI(PP) { if (a.vec32) k_stencil_gen32<PP, 1, true, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, 1, false, true><<<grid, block, smem, st>>>(a, nc, L); }
+#define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else if (a.epi.on) { QMG_G32_EPI(PP) } else { QMG_G32_CASE2(PP, 1) } } break;
         switch (pp) { QMG_G32_CASE(1) QMG_G32_CASE(2) QMG_G32_CASE(3) QMG_G32_CASE(4) QMG_G32_CASE(5) QMG_G32_CASE(6) default: break; }
 #undef QMG_G32_CASE
+#undef QMG_G32_EPI
 #undef QMG_G32_CASE2
         QMG_LAUNCH_CHECK();
+        QMG_EPI_FINISH()
         return QMG_SUCCESS;
       }
     }
@@ -1577,6 +1659,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
+  QMG_EPI_BEGIN(gx, a.nrows)
 #define QMG_GEN_CASE3(PT, M32, KR, V32)                                                                 \
     {                                                                                                   \
       if (smem > 64 * 1024)                                                                             \
@@ -1584,8 +1667,15 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       k_stencil_gen<PT, M32, KR, V32><<<grid, block, smem, st>>>(a, nc, L);                             \
     }
 #define QMG_GEN_CASE2(PT, M32, KR) { if (M32 && a.vec32) QMG_GEN_CASE3(PT, true, KR, true) else QMG_GEN_CASE3(PT, M32, KR, false) }
+#define QMG_GEN_EPI3(PT, M32, V32)                                                                      \
+    {                                                                                                   \
+      if (smem > 64 * 1024)                                                                             \
+        QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_gen<PT, M32, 1, V32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+      k_stencil_gen<PT, M32, 1, V32, true><<<grid, block, smem, st>>>(a, nc, L);                        \
+    }
+#define QMG_GEN_EPI(PT, M32) { if (M32 && a.vec32) QMG_GEN_EPI3(PT, true, true) else QMG_GEN_EPI3(PT, M32, false) }
 #define QMG_GEN_CASE1(PT, M32)                                                                          \
-    { if (kr == 8) QMG_GEN_CASE2(PT, M32, 8) else if (kr == 4) QMG_GEN_CASE2(PT, M32, 4) else QMG_GEN_CASE2(PT, M32, 1) }
+    { if (kr == 8) QMG_GEN_CASE2(PT, M32, 8) else if (kr == 4) QMG_GEN_CASE2(PT, M32, 4) else if (a.epi.on) QMG_GEN_EPI(PT, M32) else QMG_GEN_CASE2(PT, M32, 1) }
 #define QMG_GEN_CASE(PT)                                                                                \
   case PT:                                                                                              \
     if (a.mat32) QMG_GEN_CASE1(PT, true) else QMG_GEN_CASE1(PT, false)                                  \
@@ -1598,8 +1688,11 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #undef QMG_GEN_CASE
 #undef QMG_GEN_CASE1
 #undef QMG_GEN_CASE2
+#undef QMG_GEN_EPI
+#undef QMG_GEN_EPI3
 #undef QMG_GEN_CASE3
   QMG_LAUNCH_CHECK();
+  QMG_EPI_FINISH()
   return QMG_SUCCESS;
 }
 

@@ -50,6 +50,7 @@ struct WilsonArgs {
   const void* halo_hi;
   long halo_stride;
   int y_first, y_count, boundary_only;
+  Epilogue epi;            // out = other_scale other + acc_scale acc, MR dots of out (qmg_common.h); one system per launch
 };
 
 typedef float w4f __attribute__((ext_vector_type(4)));
@@ -101,9 +102,14 @@ __device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw, R s
 // One site's (fp64: one site's column c0) result from its five right-hand-side chunks xr = {+x, +y, -x, -y, own} and its four
 // links (backward ones already conjugated), then the store.  The order of operations is kernel S's (qmg_site.hip).
 // SHAPE 1: clover + hops (+ shift); 2: hops; 3: hops scaled by a.hop_scale.
-template <typename T, int SHAPE>
+// live = false: a padding lane past the end of the half row (it computed a copy of the last site so that every lane of the wavefront
+// stays active for the epilogue's wavefront sums): nothing is stored, nothing is added to the dots.  boff: byte offset of this lane's
+// chunk from the base of lhs (system offset included) -- where the epilogue's `other` / `dotv` chunks live in their vectors.
+// EPI is a compile-time switch: the launches without an epilogue keep their register count (a run-time branch cost pair2<float> 34 VGPRs and a
+// wavefront of occupancy).
+template <typename T, int SHAPE, bool EPI>
 __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4], const T (&ly)[4], T hw, T cw, bool do_shift, bool do_zero, int p, int c0,
-                                            const WilsonArgs& a, gchar* dst_chunk) {
+                                            const WilsonArgs& a, gchar* dst_chunk, long boff, bool live, double (&ed)[3]) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int NCOL = F64 ? 1 : 2;
   typedef T R;
@@ -149,27 +155,66 @@ __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4]
     o.y = c ? (recvy + owny) : (owny + recvy);
     __attribute__((address_space(1))) w2d* dst = (__attribute__((address_space(1))) w2d*)dst_chunk;
     if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
-    __builtin_nontemporal_store(o, dst);
+    if (EPI) {
+      if (a.epi.other) {
+        const w2d ov = *reinterpret_cast<const w2d*>(reinterpret_cast<const char*>(a.epi.other) + boff);
+        o.x = fma(a.epi.other_scale, ov.x, a.epi.acc_scale * o.x); o.y = fma(a.epi.other_scale, ov.y, a.epi.acc_scale * o.y);
+      } else if (a.epi.acc_scale != 1.0) { o.x *= a.epi.acc_scale; o.y *= a.epi.acc_scale; }
+      if (a.epi.dotv && live) {
+        const w2d r = *reinterpret_cast<const w2d*>(reinterpret_cast<const char*>(a.epi.dotv) + boff);
+        ed[0] = fma(r.x, o.x, ed[0]); ed[0] = fma(r.y, o.y, ed[0]);
+        ed[1] = fma(r.x, o.y, ed[1]); ed[1] = fma(-r.y, o.x, ed[1]);
+        ed[2] = fma(o.x, o.x, ed[2]); ed[2] = fma(o.y, o.y, ed[2]);
+      }
+    }
+    if (live) __builtin_nontemporal_store(o, dst);
   } else {
     w4f o;
     o.x = (float)(ax[0][0] + ax[NCOL - 1][0]); o.y = (float)(ay[0][0] + ay[NCOL - 1][0]);
     o.z = (float)(ax[0][1] + ax[NCOL - 1][1]); o.w = (float)(ay[0][1] + ay[NCOL - 1][1]);
     __attribute__((address_space(1))) w4f* dst = (__attribute__((address_space(1))) w4f*)dst_chunk;
     if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
-    __builtin_nontemporal_store(o, dst);
+    if (EPI) {
+      if (a.epi.other) {
+        const w4f ov = *reinterpret_cast<const w4f*>(reinterpret_cast<const char*>(a.epi.other) + boff);
+        const float os = (float)a.epi.other_scale, as = (float)a.epi.acc_scale;
+        o.x = fmaf(os, ov.x, as * o.x); o.y = fmaf(os, ov.y, as * o.y); o.z = fmaf(os, ov.z, as * o.z); o.w = fmaf(os, ov.w, as * o.w);
+      } else if (a.epi.acc_scale != 1.0) { const float as = (float)a.epi.acc_scale; o.x *= as; o.y *= as; o.z *= as; o.w *= as; }
+      if (a.epi.dotv && live) {   // both components of the site, accumulated in fp64 from the values as stored
+        const w4f r = *reinterpret_cast<const w4f*>(reinterpret_cast<const char*>(a.epi.dotv) + boff);
+        const double r0x = r.x, r0y = r.y, r1x = r.z, r1y = r.w, o0x = o.x, o0y = o.y, o1x = o.z, o1y = o.w;
+        ed[0] = fma(r0x, o0x, ed[0]); ed[0] = fma(r0y, o0y, ed[0]); ed[0] = fma(r1x, o1x, ed[0]); ed[0] = fma(r1y, o1y, ed[0]);
+        ed[1] = fma(r0x, o0y, ed[1]); ed[1] = fma(-r0y, o0x, ed[1]); ed[1] = fma(r1x, o1y, ed[1]); ed[1] = fma(-r1y, o1x, ed[1]);
+        ed[2] = fma(o0x, o0x, ed[2]); ed[2] = fma(o0y, o0y, ed[2]); ed[2] = fma(o1x, o1x, ed[2]); ed[2] = fma(o1y, o1y, ed[2]);
+      }
+    }
+    if (live) __builtin_nontemporal_store(o, dst);
+  }
+}
+
+// end of a kernel W launch with the MR epilogue: one partial per wavefront of the launch (system slot 0); EVERY lane calls it
+__device__ __forceinline__ void wilson_store_partials(const WilsonArgs& a, double (&ed)[3]) {
+  const double s0 = wave_sum(ed[0]), s1 = wave_sum(ed[1]), s2 = wave_sum(ed[2]);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    const long w = ((long)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    double* pp = a.epi.part + w * 4;
+    pp[0] = s0; pp[1] = s1; pp[2] = s2; pp[3] = 0.0;
   }
 }
 
 // T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only;
 // 3: hops only, entries scaled (right-block-Jacobi).
-template <typename T, int SHAPE, bool ZERO, bool BATCH>
+template <typename T, int SHAPE, bool ZERO, bool BATCH, bool EPI = false>
 __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
   typedef T R;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
-  if (j >= a.hr) return;
+  const int jt = t / LPS, c0 = F64 ? (t % LPS) : 0;
+  if (!EPI && jt >= a.hr) return;
+  const bool live = !EPI || jt < a.hr;
+  const int j = live ? jt : a.hr - 1;   // with an epilogue padding lanes shadow the last site (see wilson_site); without one they have left
+  double ed[3] = {0.0, 0.0, 0.0};
   const long sys_bytes = a.vec_stride * (long)(2 * sizeof(T));
   const R hw = (R)(-0.5 * a.w), cw = (R)(2.0 * a.w);
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
@@ -241,23 +286,27 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
     for (int k = 0; k < nsys; k++) {
       if (BATCH && k > 0) { load_x(k); __builtin_amdgcn_sched_barrier(0); }
       char* out = reinterpret_cast<char*>(a.lhs) + (long)a.ridx[k] * sys_bytes;
-      wilson_site<T, SHAPE>(xr, lx, ly, hw, cw, do_shift, do_zero, p, c0, a, uni(out + row_own) + off_j);
+      wilson_site<T, SHAPE, EPI>(xr, lx, ly, hw, cw, do_shift, do_zero, p, c0, a, uni(out + row_own) + off_j, (long)a.ridx[k] * sys_bytes + row_own + off_j, live, ed);
     }
   }
+  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
 }
 
 // Kernel W2: BOTH parities of column j on row y per lane group -- the full operator (clover + all hops on both parities).
 // Kernel W is not HBM-bound but in-flight-bound (3 KB of HBM requests per wavefront); a pair shares what the two sites
 // have in common -- each site's own chunk is an x-neighbour of the other, one back link is the other's own link: 15 loads
 // per pair instead of 18 -- and puts twice the HBM bytes of a wavefront in flight.  Per-site arithmetic = wilson_site.
-template <typename T, bool ZERO, bool BATCH>
+template <typename T, bool ZERO, bool BATCH, bool EPI = false>
 __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
   typedef T R;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
-  if (j >= a.hr) return;
+  const int jt = t / LPS, c0 = F64 ? (t % LPS) : 0;
+  if (!EPI && jt >= a.hr) return;
+  const bool live = !EPI || jt < a.hr;
+  const int j = live ? jt : a.hr - 1;   // with an epilogue padding lanes shadow the last site (see wilson_site); without one they have left
+  double ed[3] = {0.0, 0.0, 0.0};
   const long sys_bytes = a.vec_stride * (long)(2 * sizeof(T));
   const R hw = (R)(-0.5 * a.w), cw = (R)(2.0 * a.w);
   constexpr unsigned CH = 16u * LPS, GB = 2u * sizeof(T);
@@ -320,30 +369,34 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
         const LK bxE = sE ? uxO : ubx;                   // Ux at the even site's -x neighbour (an odd site at jmE = j + sE - 1)
         const R lxE[4] = {(R)uxE.x, (R)uyE.x, (R)bxE.x, (R)ubyE.x}, lyE[4] = {(R)uxE.y, (R)uyE.y, -(R)bxE.y, -(R)ubyE.y};
         const w4f xrE[5] = {sE ? othO : ownO, upE, sE ? ownO : othO, dnE, ownE};
-        wilson_site<T, 1>(xrE, lxE, lyE, hw, cw, shE, zE, 0, c0, a, uni(out + rowE) + off_j);
+        wilson_site<T, 1, EPI>(xrE, lxE, lyE, hw, cw, shE, zE, 0, c0, a, uni(out + rowE) + off_j, (long)a.ridx[k] * sys_bytes + rowE + off_j, live, ed);
       }
       {
         const LK bxO = sE ? ubx : uxE;                   // Ux at the odd site's -x neighbour (an even site at jmO = j - sE)
         const R lxO[4] = {(R)uxO.x, (R)uyO.x, (R)bxO.x, (R)ubyO.x}, lyO[4] = {(R)uxO.y, (R)uyO.y, -(R)bxO.y, -(R)ubyO.y};
         const w4f xrO[5] = {sE ? ownE : othE, upO, sE ? othE : ownE, dnO, ownO};
-        wilson_site<T, 1>(xrO, lxO, lyO, hw, cw, shO, zO, 1, c0, a, uni(out + rowO) + off_j);
+        wilson_site<T, 1, EPI>(xrO, lxO, lyO, hw, cw, shO, zO, 1, c0, a, uni(out + rowO) + off_j, (long)a.ridx[k] * sys_bytes + rowO + off_j, live, ed);
       }
     }
   }
+  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
 }
 
 // Kernel W2 on TWO consecutive rows per lane group (one system): rows y and y + 1 are each other's +-y neighbours and back-y
 // links, so the four sites take 12 + 12 loads instead of 2 x (8 + 7), and -- what matters for a kernel that is bound by the
 // bytes a wavefront has in flight -- every wavefront requests 12 KB of HBM data instead of 6 (at 3 resident wavefronts per SIMD
 // instead of 4).  Per-site arithmetic = wilson_site, so the results are the one-row kernel's bit for bit.
-template <typename T, bool ZERO>
+template <typename T, bool ZERO, bool EPI = false>
 __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
   typedef T R;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = t / LPS, c0 = F64 ? (t % LPS) : 0;
-  if (j >= a.hr) return;
+  const int jt = t / LPS, c0 = F64 ? (t % LPS) : 0;
+  if (!EPI && jt >= a.hr) return;
+  const bool live = !EPI || jt < a.hr;
+  const int j = live ? jt : a.hr - 1;   // with an epilogue padding lanes shadow the last site (see wilson_site); without one they have left
+  double ed[3] = {0.0, 0.0, 0.0};
   const long sys_bytes = a.vec_stride * (long)(2 * sizeof(T));
   const R hw = (R)(-0.5 * a.w), cw = (R)(2.0 * a.w);
   constexpr unsigned CH = 16u * LPS, GB = 2u * sizeof(T);
@@ -402,27 +455,35 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
       const LK bx = sA ? uxOA : ubxA;
       const R lx[4] = {(R)uxEA.x, (R)uyEA.x, (R)bx.x, (R)ubyEA.x}, ly[4] = {(R)uxEA.y, (R)uyEA.y, -(R)bx.y, -(R)ubyEA.y};
       const w4f xr[5] = {sA ? othOA : ownOA, ownOB, sA ? ownOA : othOA, dnEA, ownEA};
-      wilson_site<T, 1>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEA) + off_j);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEA) + off_j, off + rowEA + off_j, live, ed);
     }
     {   // row A, odd site
       const LK bx = sA ? ubxA : uxEA;
       const R lx[4] = {(R)uxOA.x, (R)uyOA.x, (R)bx.x, (R)ubyOA.x}, ly[4] = {(R)uxOA.y, (R)uyOA.y, -(R)bx.y, -(R)ubyOA.y};
       const w4f xr[5] = {sA ? ownEA : othEA, ownEB, sA ? othEA : ownEA, dnOA, ownOA};
-      wilson_site<T, 1>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOA) + off_j);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOA) + off_j, off + rowOA + off_j, live, ed);
     }
     {   // row B, even site: -y = the odd site of row A, back-y link = that site's Uy
       const LK bx = sB ? uxOB : ubxB;
       const R lx[4] = {(R)uxEB.x, (R)uyEB.x, (R)bx.x, (R)uyOA.x}, ly[4] = {(R)uxEB.y, (R)uyEB.y, -(R)bx.y, -(R)uyOA.y};
       const w4f xr[5] = {sB ? othOB : ownOB, upEB, sB ? ownOB : othOB, ownOA, ownEB};
-      wilson_site<T, 1>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEB) + off_j);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEB) + off_j, off + rowEB + off_j, live, ed);
     }
     {   // row B, odd site
       const LK bx = sB ? ubxB : uxEB;
       const R lx[4] = {(R)uxOB.x, (R)uyOB.x, (R)bx.x, (R)uyEA.x}, ly[4] = {(R)uxOB.y, (R)uyOB.y, -(R)bx.y, -(R)uyEA.y};
       const w4f xr[5] = {sB ? ownEB : othEB, upOB, sB ? othEB : ownEB, ownEA, ownOB};
-      wilson_site<T, 1>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOB) + off_j);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOB) + off_j, off + rowOB + off_j, live, ed);
     }
   }
+  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
+}
+
+template <typename T>
+static void launch_wilson_epi(const WilsonArgs& a, int shape, dim3 grid, hipStream_t st) {   // one system, overwrite, with the epilogue
+  if (shape == 1) k_wilson_direct<T, 1, true, false, true><<<grid, BLOCK, 0, st>>>(a);
+  else if (shape == 3) k_wilson_direct<T, 3, true, false, true><<<grid, BLOCK, 0, st>>>(a);
+  else k_wilson_direct<T, 2, true, false, true><<<grid, BLOCK, 0, st>>>(a);
 }
 
 template <typename T, bool BATCH>
@@ -438,7 +499,7 @@ using namespace qmg;
 
 static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, bool scaled, double hop_scale,
                               void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride,
-                              size_t halo_stride, unsigned mask, int rows, void* stream);
+                              size_t halo_stride, unsigned mask, int rows, void* stream, const qmg_apply_epilogue* epi = nullptr);
 
 extern "C" {
 
@@ -468,11 +529,29 @@ int qmg_wilson_apply_direct(int dtype, const qmg_stencil_desc* d, const void* ga
                             stream);
 }
 
+// The same two entry points with an EPILOGUE on the finished site values (include/qmg_hip.h: qmg_apply_epilogue; qmg_stencil_apply_epi_t is the
+// form for the stored stencils): ONE system per launch (exactly one bit of `mask`), overwrite semantics on the processed parities, rows = 0.
+int qmg_wilson_apply_direct_epi(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, void* lhs, const void* rhs,
+                                const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride, unsigned mask,
+                                const qmg_apply_epilogue* epi, void* stream) {
+  if (!epi) return QMG_ERR_INVALID;
+  return wilson_direct_impl(dtype, d, gauge, gauge_Ly, y0, wilson_coeff, false, 1.0, lhs, rhs, halo_lo, halo_hi, pieces, nrhs, vec_stride, halo_stride, mask, 0,
+                            stream, epi);
+}
+int qmg_wilson_hops_direct_epi(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, double hop_scale, void* lhs,
+                               const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride, size_t halo_stride,
+                               unsigned mask, const qmg_apply_epilogue* epi, void* stream) {
+  if (!epi) return QMG_ERR_INVALID;
+  if (pieces & (QMG_P_CLOVER | QMG_P_SHIFT)) return QMG_ERR_UNSUPPORTED;
+  return wilson_direct_impl(dtype, d, gauge, gauge_Ly, y0, wilson_coeff, true, hop_scale, lhs, rhs, halo_lo, halo_hi, pieces, nrhs, vec_stride, halo_stride, mask,
+                            0, stream, epi);
+}
+
 }  // extern "C"
 
 static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* gauge, int gauge_Ly, int y0, double wilson_coeff, bool scaled, double hop_scale,
                               void* lhs, const void* rhs, const void* halo_lo, const void* halo_hi, unsigned pieces, int nrhs, size_t vec_stride,
-                              size_t halo_stride, unsigned mask, int rows, void* stream) {
+                              size_t halo_stride, unsigned mask, int rows, void* stream, const qmg_apply_epilogue* epi) {
   if (!valid_dtype(dtype) || !d || !gauge || !lhs || !rhs || nrhs < 1 || nrhs > 16 || rows < 0 || rows > 2) return QMG_ERR_INVALID;
   if (!valid_lattice(d->Lx, d->Ly) || !valid_lattice(d->Lx, gauge_Ly) || y0 < 0 || (y0 & 1) || y0 + d->Ly > gauge_Ly) return QMG_ERR_INVALID;
   if (d->nc != 2) return QMG_ERR_UNSUPPORTED;
@@ -489,6 +568,13 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
   for (int k = 0; k < nrhs; k++)
     if ((mask >> k) & 1u) a.ridx[a.nrhs++] = k;
   if (a.nrhs == 0) return QMG_SUCCESS;
+  a.epi = no_epilogue();
+  if (epi) {
+    if (a.nrhs != 1) return QMG_ERR_UNSUPPORTED;      // one system per launch
+    if (epi->other == lhs || epi->dotv == lhs) return QMG_ERR_INVALID;
+    a.epi.on = 1;
+    a.epi.other = epi->other; a.epi.other_scale = epi->other_scale; a.epi.acc_scale = epi->acc_scale; a.epi.dotv = epi->dotv;
+  }
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
   const unsigned even_bits = QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E;
   const unsigned odd_bits = QMG_P_CLOVER_O | QMG_P_OE | QMG_P_SHIFT_O | QMG_P_ZERO_O;
@@ -515,22 +601,41 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
   if (shape == 0 || (scaled && shape != 2)) return QMG_ERR_UNSUPPORTED;
   if (scaled) shape = 3;
   if (lhs == rhs && (shape == 1 || a.par_count == 2)) return QMG_ERR_INVALID;
+  if (epi && (!zero || lhs == rhs)) return QMG_ERR_INVALID;   // an epilogue needs overwrite semantics and a separate output
   const int lps = dtype == QMG_C64 ? 2 : 1;
   const long lanes = (long)a.hr * lps;
   dim3 grid((unsigned)((lanes + BLOCK - 1) / BLOCK), a.nrows > 65535 ? 65535u : (unsigned)a.nrows);
   hipStream_t st = as_stream(stream);
+  // the epilogue's dot partials: one per wavefront of the launch that is chosen below
+  long epi_npart = 0;
+  auto epi_begin = [&](dim3 g) -> bool {
+    if (!(a.epi.on && a.epi.dotv)) return true;
+    epi_npart = (long)g.x * (long)g.y * (BLOCK / WAVE);
+    a.epi.part = mr_epilogue_begin(1, epi_npart);
+    a.epi.npart = epi_npart;
+    return a.epi.part != nullptr;
+  };
+  auto epi_finish = [&]() -> int {
+    if (!epi_npart) return QMG_SUCCESS;
+    const unsigned char id0 = (unsigned char)a.ridx[0];
+    return mr_epilogue_finish(&id0, 1, epi_npart, st);
+  };
   if (shape == 1 && a.par_count == 2 && g_wilson_pair >= 2 && a.nrhs == 1 && !a.boundary_only && a.y_count % 2 == 0) {
     // one system, an even run of consecutive rows: kernel W2 on two rows per lane group
     const int ny = a.y_count / 2;   // (capping grid.y -- a row-pair loop per block -- changes nothing: 0.29-0.31 ms at every cap)
     dim3 gridp(grid.x, ny > 65535 ? 65535u : (unsigned)ny);
-    if (dtype == QMG_C64) { if (zero) k_wilson_pair2<double, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<double, false><<<gridp, BLOCK, 0, st>>>(a); }
+    if (!epi_begin(gridp)) return QMG_ERR_HIP;
+    if (a.epi.on) { if (dtype == QMG_C64) k_wilson_pair2<double, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<float, true, true><<<gridp, BLOCK, 0, st>>>(a); }
+    else if (dtype == QMG_C64) { if (zero) k_wilson_pair2<double, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<double, false><<<gridp, BLOCK, 0, st>>>(a); }
     else { if (zero) k_wilson_pair2<float, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<float, false><<<gridp, BLOCK, 0, st>>>(a); }
     QMG_LAUNCH_CHECK();
-    return QMG_SUCCESS;
+    return epi_finish();
   }
   if (shape == 1 && a.par_count == 2 && g_wilson_pair) {   // the full operator: both parities of a column per lane group (kernel W2)
     dim3 gridp(grid.x, a.y_count > 65535 ? 65535u : (unsigned)a.y_count);
-    if (dtype == QMG_C64) {
+    if (!epi_begin(gridp)) return QMG_ERR_HIP;
+    if (a.epi.on) { if (dtype == QMG_C64) k_wilson_pair<double, true, false, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<float, true, false, true><<<gridp, BLOCK, 0, st>>>(a); }
+    else if (dtype == QMG_C64) {
       if (a.nrhs == 1) { if (zero) k_wilson_pair<double, true, false><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, false><<<gridp, BLOCK, 0, st>>>(a); }
       else { if (zero) k_wilson_pair<double, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, true><<<gridp, BLOCK, 0, st>>>(a); }
     } else {
@@ -538,10 +643,12 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
       else { if (zero) k_wilson_pair<float, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<float, false, true><<<gridp, BLOCK, 0, st>>>(a); }
     }
     QMG_LAUNCH_CHECK();
-    return QMG_SUCCESS;
+    return epi_finish();
   }
-  if (dtype == QMG_C64) { if (a.nrhs == 1) launch_wilson_b<double, false>(a, shape, zero, grid, st); else launch_wilson_b<double, true>(a, shape, zero, grid, st); }
+  if (!epi_begin(grid)) return QMG_ERR_HIP;
+  if (a.epi.on) { if (dtype == QMG_C64) launch_wilson_epi<double>(a, shape, grid, st); else launch_wilson_epi<float>(a, shape, grid, st); }
+  else if (dtype == QMG_C64) { if (a.nrhs == 1) launch_wilson_b<double, false>(a, shape, zero, grid, st); else launch_wilson_b<double, true>(a, shape, zero, grid, st); }
   else { if (a.nrhs == 1) launch_wilson_b<float, false>(a, shape, zero, grid, st); else launch_wilson_b<float, true>(a, shape, zero, grid, st); }
   QMG_LAUNCH_CHECK();
-  return QMG_SUCCESS;
+  return epi_finish();
 }

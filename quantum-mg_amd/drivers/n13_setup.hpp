@@ -107,7 +107,8 @@ inline int N13::build(int argc, char** argv) {
   const bool dd = qmg::slab().on;
   const bool root = !dd || qmg::slab().rank == 0;
   if (!dd && !qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
-  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; std::cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
+  // Galerkin matrices of the preconditioner levels are STORED as complex<float> by default (multigrid.hpp); QMG_COARSE_F32=0 keeps them fp64
+  if (getenv("QMG_COARSE_F32")) MultigridMG::coarse_f32_storage() = atoi(getenv("QMG_COARSE_F32")) != 0 ? 1 : 0;
   x_len = stoi(argv[1]); y_len = stoi(argv[1]);
   mass = stod(argv[2]);
   const double beta = stod(argv[3]);
@@ -242,6 +243,7 @@ inline int N13::build(int argc, char** argv) {
     if (root) cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
   }
   qmg_stream_sync(0);
+  if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
   if (root) cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
        << " s ; total " << setup_s << " s\n" << setprecision(20);

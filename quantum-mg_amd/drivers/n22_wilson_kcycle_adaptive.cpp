@@ -118,7 +118,8 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
     if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env")) return 2;
     cout << "[QMG-INFO]: rank " << rank << " of " << world << " on device " << local_rank << "\n";
   }
-  if (getenv("QMG_COARSE_F32")) { MultigridMG::coarse_f32_storage() = true; cout << "[QMG-INFO]: coarse operators stored as complex<float> (opt-in)\n"; }
+  // Galerkin matrices of the preconditioner levels are STORED as complex<float> by default (multigrid.hpp); QMG_COARSE_F32=0 keeps them fp64
+  if (getenv("QMG_COARSE_F32")) MultigridMG::coarse_f32_storage() = atoi(getenv("QMG_COARSE_F32")) != 0 ? 1 : 0;
   const int x_len = stoi(argv[1]), y_len = x_len;
   const double mass = stod(argv[2]);
   const int n_refine = stoi(argv[4]);

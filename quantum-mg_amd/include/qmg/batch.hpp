@@ -39,6 +39,13 @@ namespace qmg {
 
 const int BATCH_MAX = 16;
 
+// The K-cycle's fixed-count smoothers with their scalars on the device (bmr_fixed_zero_guess).  QMG_KCYCLE_DEVICE_SCALARS=0 restores
+// the host-scalar loops (bminv_vector_minres_zero_guess: one host round trip per MR iteration, residual recomputed): A/B runs.
+inline bool kcycle_device_scalars() {
+  static const bool on = !(getenv("QMG_KCYCLE_DEVICE_SCALARS") && atoi(getenv("QMG_KCYCLE_DEVICE_SCALARS")) == 0);
+  return on;
+}
+
 template <typename T> struct dtype_of;
 template <> struct dtype_of<double> { enum { value = QMG_C64 }; };
 template <> struct dtype_of<float> { enum { value = QMG_C32 }; };
@@ -211,13 +218,65 @@ inline void apply_stencil_typed_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, un
   if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch<T>(op->st, lhs, rhs, mask);
   else apply_M_overwrite_batch_t<T>(op->st, lhs, rhs, mask);
 }
+// ---- the same applies with an EPILOGUE (Stencil2D::launch_set_epi), system by system, when ONE system is active: the BLAS-1 pass that
+// would follow the apply (residual, Schur combination, MR dots) happens on the finished site values inside the apply's launch.  A batch
+// of several active systems keeps the shared-matrix batch kernels and the separate passes.
+namespace qmg {
+inline int single_active(unsigned mask, int nrhs) {   // the index of the one active system, or -1
+  int k = -1;
+  for (int i = 0; i < nrhs; i++) if (is_active(mask, i)) { if (k >= 0) return -1; k = i; }
+  return k;
+}
+}  // namespace qmg
+// out = b - A x (dotv == 0), or p = A r with the MR dots <p,r>, <p,p> left in the device slot (b == 0, mr_dots): true if done in fused launches
+template <typename T>
+inline bool apply_op_fused(BatchOp* op, qmg::BatchT<T> out, qmg::BatchT<T> x, const qmg::BatchT<T>* b, bool mr_dots, unsigned mask) {
+  const int k = qmg::single_active(mask, out.nrhs);
+  if (k < 0) return false;
+  Stencil2D* st = op->st;
+  qmg_apply_epilogue e;
+  if (op->type == QMG_MATVEC_ORIGINAL) {
+    // b - A x: out = 1 b + (-1) acc ; MR: out = acc, dots against x (= r)
+    e.other = b ? (const void*)b->p : 0; e.other_scale = 1.0; e.acc_scale = b ? -1.0 : 1.0; e.dotv = mr_dots ? (const void*)x.p : 0;
+    return st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, x.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e);
+  }
+  if (op->type != QMG_MATVEC_RIGHT_SCHUR || !st->built_rbjacobi) return false;
+  // Schur: A x = x_e - D'_eo D'_oe x_e.  First half plain (t_o = D'_oe x_e), second half with the epilogue on the even sites:
+  //   A x      = 1 x_e + (-1) D'_eo t          (MR: dots against x_e)
+  //   b - A x  = (b_e - x_e) + D'_eo t  -- two `other` vectors: not one epilogue; the residual form is left to the separate passes
+  if (b) return false;
+  qmg::BatchPoolT<T> pool(out.stride, out.nrhs);
+  qmg::BatchT<T> t = pool.get();
+  if (!t.p) return false;
+  st->launch_set_batch<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, x.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, out.nrhs, out.stride, mask);
+  e.other = x.p; e.other_scale = 1.0; e.acc_scale = -1.0; e.dotv = mr_dots ? (const void*)x.p : 0;
+  if (st->launch_set_epi<T>(QMG_P_EO | QMG_P_ZERO_E, out.p, t.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, out.stride, k, e)) return true;
+  // not served: finish the unfused way (t_o is already there)
+  st->launch_set_batch<T>(QMG_P_EO | QMG_P_ZERO_E, t.p, t.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, out.nrhs, out.stride, mask);
+  qmg::bxmyz(x, t, out, (size_t)st->lat->get_size_cv_l() / 2, mask);
+  if (mr_dots) qmg::ok(qmg_batch_mr_dots_t(qmg::dtype_of<T>::value, x.p, out.p, (size_t)st->lat->get_size_cv_l() / 2, out.nrhs, out.stride, mask, qmg::current_stream()), "qmg_batch_mr_dots");
+  return true;
+}
+// out = b - A x over the operator's solve size, fused where served
+template <typename T>
+inline void apply_op_residual(BatchOp* op, qmg::BatchT<T> out, qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T> scratch, size_t size_solve, unsigned mask) {
+  if (apply_op_fused<T>(op, out, x, &b, false, mask)) return;
+  apply_stencil_typed_batch<T>(scratch, x, mask, (void*)op);
+  qmg::bxmyz(b, scratch, out, size_solve, mask);
+}
+
 // b_prep = prepare_M(b) (stencil_2d.h:2455-2490), b_prep OVERWRITTEN over the full vector
 template <typename T>
 inline void prepare_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<T> b_prep, qmg::BatchT<T> b, unsigned mask) {
   const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
   if (type == QMG_MATVEC_RIGHT_SCHUR) {   // b_e - D'_eo b_o on the even half, zero on the odd half (:1912-1928)
-    st->launch_set_batch<T>(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, b.nrhs, b.stride, mask);
-    qmg::bxmyz(b, b_prep, b_prep, half, mask);
+    const int k1 = qmg::single_active(mask, b.nrhs);
+    qmg_apply_epilogue e;
+    e.other = b.p; e.other_scale = 1.0; e.acc_scale = -1.0; e.dotv = 0;
+    if (k1 < 0 || !st->launch_set_epi<T>(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, b.stride, k1, e)) {
+      st->launch_set_batch<T>(QMG_P_EO | QMG_P_ZERO_E, b_prep.p, b.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, b.nrhs, b.stride, mask);
+      qmg::bxmyz(b, b_prep, b_prep, half, mask);
+    }
     qmg::bzero(batch_odd_half(b_prep, half), cv - half, mask);
   } else qmg::bcopy(b_prep, b, cv, mask);
 }
@@ -228,8 +287,13 @@ inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<
   if (type == QMG_MATVEC_RIGHT_SCHUR) {   // (:1932-1957) t_o = b_o - D'_oe y_e ; t_e = y_e ; x = C^-1 t
     qmg::BatchPoolT<T> pool(x.stride, x.nrhs);
     qmg::BatchT<T> t = pool.get();
-    st->launch_set_batch<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
-    qmg::bxmyz(batch_odd_half(b, half), batch_odd_half(t, half), batch_odd_half(t, half), cv - half, mask);
+    const int k1 = qmg::single_active(mask, x.nrhs);
+    qmg_apply_epilogue e;
+    e.other = b.p; e.other_scale = 1.0; e.acc_scale = -1.0; e.dotv = 0;   // t_o = b_o - D'_oe y_e on the finished odd sites
+    if (k1 < 0 || !st->launch_set_epi<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, x.stride, k1, e)) {
+      st->launch_set_batch<T>(QMG_P_OE | QMG_P_ZERO_O, t.p, y.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+      qmg::bxmyz(batch_odd_half(b, half), batch_odd_half(t, half), batch_odd_half(t, half), cv - half, mask);
+    }
     qmg::bcopy(t, y, half, mask);
     st->launch_set_batch<T>(QMG_P_CLOVER | QMG_P_ZERO, x.p, t.p, Stencil2D::QMG_ARR_RBJ_CINV, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
   } else qmg::bcopy(x, y, cv, mask);
@@ -295,6 +359,40 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::BatchT<T>
   }
   for (int k = 0; k < nrhs; k++) { inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = "MinRes (batch)"; }
   return inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MR(omega) with a FIXED iteration count and every scalar on the device (qmg_batch_mr_dots_t / qmg_batch_mr_update_t): the form the
+// K-cycle's smoothers take.  Their tolerance (1e-15 in n13 / n19 / n22, 1e-20 in LevelSolveMG's defaults) is below what the
+// recursive residual of a few MR steps can reach in fp64, so minv_vector_minres always runs its `max_iter` iterations and NO host
+// decision depends on <p,r> / <p,p>: alpha is formed on the device and the per-iteration host round trip disappears.  The
+// arithmetic is that of bminv_vector_minres_zero_guess, operation for operation (same reduction order, same alpha = (omega <p,r>) / <p,p>).
+//   x0 = 0 is implied: x is WRITTEN by the first step (x = alpha b; no zero fill, no read) -- with iters == 0, x = 0.
+//   r_out (optional): the recursive residual b - A x after the last step (the K-cycle's pre-smoother wants it: it IS the residual the
+//   reference recomputes with one more apply, stateful_multigrid.h:863-866, up to rounding); without it the last residual update is skipped.
+// Returns the number of operator applications per active system.
+// ---------------------------------------------------------------------------------------------
+namespace qmg {
+inline bool mr_tolerance_unreachable(double eps) { return eps <= 1e-14; }
+}  // namespace qmg
+template <typename T>
+inline int bmr_fixed_zero_guess(qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T>* r_out, int size, int iters, double omega,
+                                batch_matrix_op_t<T> matrix_vector, void* extra_info, unsigned mask, BatchOp* fused_op = 0) {
+  if (iters <= 0) { qmg::bzero(x, (size_t)size, mask); if (r_out) qmg::bcopy(*r_out, b, (size_t)size, mask); return 0; }
+  qmg::BatchPoolT<T> pool(x.stride, x.nrhs);
+  qmg::BatchT<T> p = pool.get();
+  qmg::BatchT<T> r = r_out ? *r_out : ((iters > 1) ? pool.get() : qmg::BatchT<T>());
+  const int dt = qmg::dtype_of<T>::value;
+  for (int it = 0; it < iters; it++) {
+    const qmg::BatchT<T>& rin = (it == 0) ? b : r;
+    if (!(fused_op && apply_op_fused<T>(fused_op, p, rin, (const qmg::BatchT<T>*)0, true, mask))) {   // p = A r and its dots in one pass, where served
+      matrix_vector(p, rin, mask, extra_info);
+      qmg::ok(qmg_batch_mr_dots_t(dt, rin.p, p.p, (size_t)size, x.nrhs, x.stride, mask, qmg::current_stream()), "qmg_batch_mr_dots");
+    }
+    const bool want_r = (it + 1 < iters) || r_out;
+    qmg::ok(qmg_batch_mr_update_t(dt, omega, x.p, rin.p, want_r ? r.p : 0, p.p, it == 0, (size_t)size, x.nrhs, x.stride, mask, qmg::current_stream()), "qmg_batch_mr_update");
+  }
+  return iters;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,7 +626,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
     for (int k = 0; k < nrhs; k++) {
       if (!qmg::is_active(upd, k)) continue;
       its[k]++;
-      if (verb && verb->verbosity == VERB_DETAIL) std::cout << verb->verb_prefix << name << " rhs " << k << " Iter " << its[k] << " RelTol " << std::sqrt(rsq[k]) / bnorm[k] << "\n";
+      if (verb && verb->verbosity == VERB_DETAIL) { std::cout << verb->verb_prefix << name; if (nrhs > 1) std::cout << " rhs " << k; std::cout << " Iter " << its[k] << " RelTol " << std::sqrt(rsq[k]) / bnorm[k] << "\n"; }
       if (std::sqrt(rsq[k]) < epsv[k] * bnorm[k]) { conv[k] = true; act &= ~(1u << k); }
     }
     if (kb == basis_max) flush_x();   // the basis is about to be reused: bring every pending x up to date (frozen systems too)
@@ -549,8 +647,11 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
   flush_x();
   for (int k = 0; k < nrhs; k++) {
     inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = name;
-    if (verb && verb->verbosity != VERB_NONE && qmg::is_active(mask, k))
-      std::cout << verb->verb_prefix << name << " rhs " << k << (conv[k] ? " Success " : " Fail ") << "Iter " << its[k] << " RelTol " << (bnorm[k] > 0 ? std::sqrt(rsq[k]) / bnorm[k] : 0.0) << "\n";
+    if (verb && verb->verbosity != VERB_NONE && qmg::is_active(mask, k)) {   // (one system: krylov.hpp's line, word for word)
+      std::cout << verb->verb_prefix << name;
+      if (nrhs > 1) std::cout << " rhs " << k;
+      std::cout << (conv[k] ? " Success " : " Fail ") << "Iter " << its[k] << " RelTol " << (bnorm[k] > 0 ? std::sqrt(rsq[k]) / bnorm[k] : 0.0) << "\n";
+    }
   }
   return inv;
 }
@@ -632,8 +733,14 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) nact++;
 
   // ---- 1. pre-smooth: A z1 ~ rhs, r1 = rhs - A z1
-  qmg::bzero(z1, fine_size, mask);
-  if (level_solve->pre_iters > 0) {
+  const bool fixed_pre = level_solve->pre_iters > 0 && qmg::mr_tolerance_unreachable(level_solve->pre_tol) && qmg::kcycle_device_scalars();
+  if (fixed_pre) {
+    // fixed-count MR, scalars on the device; its recursive residual is r1 (the reference recomputes rhs - A z1 with one more
+    // apply, stateful_multigrid.h:863-866: the same vector up to rounding), so the smoother costs pre_iters applies, not pre_iters + 1
+    const int nops = bmr_fixed_zero_guess<T>(z1, rhs, &r1, (int)fine_size_solve, level_solve->pre_iters, 0.85, apply_stencil_typed_batch<T>, (void*)&fine_op, mask, &fine_op);
+    mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nops * nact, level);
+  } else if (level_solve->pre_iters > 0) {
+    qmg::bzero(z1, fine_size, mask);
     std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z1, rhs, (int)fine_size_solve, level_solve->pre_iters, level_solve->pre_tol, 0.85,
                                                                          apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
     count(QMG_DSLASH_TYPE_PRESMOOTH, inv, level);
@@ -641,6 +748,7 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
     mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
     qmg::bxmyz(rhs, Atmp, r1, fine_size_solve, mask);
   } else {
+    qmg::bzero(z1, fine_size, mask);
     qmg::bcopy(r1, rhs, fine_size_solve, mask);
     qmg::bcopy(z1, rhs, fine_size_solve, mask);
   }
@@ -684,15 +792,31 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
 
   // ---- 4. post-smooth on r2 = rhs - A lhs
   if (level_solve->post_iters > 0) {
-    apply_stencil_typed_batch<T>(Atmp, lhs, mask, (void*)&fine_op);
     qmg::BatchT<T> r2 = z2, z3 = z1;   // both free again
-    qmg::bxmyz(rhs, Atmp, r2, fine_size_solve, mask);
-    qmg::bzero(z3, fine_size, mask);
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
-                                                                         apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
-    count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
+    apply_op_residual<T>(&fine_op, r2, lhs, rhs, Atmp, fine_size_solve, mask);   // r2 = rhs - A lhs
+    if (qmg::mr_tolerance_unreachable(level_solve->post_tol) && qmg::kcycle_device_scalars()) {
+      const int nops = bmr_fixed_zero_guess<T>(z3, r2, (qmg::BatchT<T>*)0, (int)fine_size_solve, level_solve->post_iters, 0.85, apply_stencil_typed_batch<T>, (void*)&fine_op, mask, &fine_op);
+      mg->add_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, nops * nact, level);
+    } else {
+      qmg::bzero(z3, fine_size, mask);
+      std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
+                                                                           apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
+      count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
+    }
     qmg::bcxpy(z3, lhs, fine_size_solve, mask);
   }
+}
+
+// StatefulMultigridMG::mg_preconditioner for one system through this engine (declared in multigrid.hpp).  QMG_KCYCLE_ENGINE=single
+// keeps the single-vector implementation of multigrid.hpp (A/B runs, and the reference-shaped code path for the parity tests).
+inline bool qmg_kcycle_via_batch(StatefulMultigridMG* mg, complex<double>* lhs, complex<double>* rhs, int size, inversion_verbose_struct* verb) {
+  static const bool on = !(getenv("QMG_KCYCLE_ENGINE") && std::string(getenv("QMG_KCYCLE_ENGINE")) == "single");
+  if (!on || qmg::slab().on) return false;
+  BatchKcycle bk(mg, 1);
+  if (!bk.supported()) return false;
+  const size_t stride = (size_t)mg->get_lattice(mg->get_multigrid_level())->get_size_cv_l();
+  mg_preconditioner_batch<double>(qmg::Batch(lhs, stride, 1), qmg::Batch(rhs, stride, 1), size, 1u, (void*)&bk, verb);
+  return true;
 }
 
 // The fp32 K-cycle as the preconditioner of an fp64 flexible outer solve (BASELINE configs[4] "fp32"): the residual of

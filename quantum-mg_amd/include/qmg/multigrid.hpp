@@ -96,11 +96,24 @@ class MultigridMG {
   }
 
  public:
-  // OPT-IN (default off; not in the reference): every Galerkin coarse operator built from now on keeps a complex<float>
-  // copy of its matrices and streams that in ORIGINAL-operator applies (Stencil2D::enable_f32_matrices).  The hierarchy
-  // then only preconditions in reduced storage precision; the outer fp64 flexible solver still converges to its fp64
-  // tolerance.  Drivers switch it on with QMG_COARSE_F32=1.
-  static bool& coarse_f32_storage() { static bool f = false; return f; }
+  // Storage precision of the Galerkin coarse operators (not in the reference, which is fp64 throughout): with it ON every coarse
+  // operator built from now on keeps a complex<float> copy of its matrices and streams that in ORIGINAL-operator applies
+  // (Stencil2D::enable_f32_matrices) -- half the bytes of an HBM-bound apply.  Vectors, shifts, arithmetic and the Galerkin
+  // builds stay fp64; an apply then equals the fp64 apply of the ROUNDED matrices (relative 6e-8 per entry).
+  //   -1 (default): ON for a StatefulMultigridMG -- a hierarchy that only PRECONDITIONS a flexible fp64 outer solve, whose true
+  //      residual still reaches its fp64 tolerance (C3: the same 13 outer iterations, 1e-10) -- and OFF for a plain MultigridMG,
+  //      whose coarse operators are used as operators (Galerkin identity R A P to 1e-15: n08);
+  //    0 / 1: off / on for both (drivers: QMG_COARSE_F32=0 / 1).
+  static int& coarse_f32_storage() { static int f = -1; return f; }
+  virtual bool coarse_f32_default() const { return false; }
+  // (y-slab mode keeps fp64 coarse matrices: the slab kernels stream the fp64 arrays; nc = 1, 2, 4 have no fp32-stored kernel)
+  bool coarse_f32_wanted(int nc) const {
+    if (qmg::slab().on || nc == 1 || nc == 2 || nc == 4) return false;
+    const int f = coarse_f32_storage();
+    return f < 0 ? coarse_f32_default() : f != 0;
+  }
+  // true if any level of this hierarchy streams complex<float> Galerkin matrices (drivers print it)
+  bool any_coarse_f32() { for (int i = 1; i < num_levels; i++) if (stencil_list[i] && stencil_list[i]->f32_matrices) return true; return false; }
 
   enum QMGMultigridPrecondStencil { QMG_MULTIGRID_PRECOND_ORIGINAL = 0, QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI = 1 };
 
@@ -136,7 +149,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list.push_back(new CoarseOperator2D(new_lat, stencil_list[num_levels - 2], lattice_list[num_levels - 2], new_transfer, is_chiral,
                                                   build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra));
-      if (coarse_f32_storage()) stencil_list.back()->enable_f32_matrices();
+      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list.back()->enable_f32_matrices();
       is_stencil_managed.push_back(true);
     } else {
       stencil_list.push_back(0);
@@ -182,7 +195,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list[level] = new CoarseOperator2D(new_lat, stencil_list[level - 1], lattice_list[level - 1], new_transfer, is_chiral,
                                                  build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra);
-      if (coarse_f32_storage()) stencil_list[level]->enable_f32_matrices();
+      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list[level]->enable_f32_matrices();
       is_stencil_managed[level] = true;
     } else {
       stencil_list[level] = 0;
@@ -225,6 +238,9 @@ class MultigridMG {
 };
 
 // ---------------- solve state + K-cycle (stateful_multigrid.h) ----------------
+class StatefulMultigridMG;
+// batch.hpp: the K-cycle engine every supported configuration runs on (one system = a batch of one); false = not served there
+inline bool qmg_kcycle_via_batch(StatefulMultigridMG* mg, complex<double>* lhs, complex<double>* rhs, int size, inversion_verbose_struct* verb);
 enum QMGDslashType { QMG_DSLASH_TYPE_NULLVEC = 0, QMG_DSLASH_TYPE_KRYLOV = 1, QMG_DSLASH_TYPE_PRESMOOTH = 2, QMG_DSLASH_TYPE_POSTSMOOTH = 3 };
 
 class StatefulMultigridMG : public MultigridMG {
@@ -286,6 +302,7 @@ class StatefulMultigridMG : public MultigridMG {
     dslash_tracker_list.push_back(new DslashTrackerMG());
   }
   ~StatefulMultigridMG() { for (size_t i = 0; i < dslash_tracker_list.size(); i++) delete dslash_tracker_list[i]; }
+  virtual bool coarse_f32_default() const { return true; }   // this hierarchy is a preconditioner (mg_preconditioner)
 
   void set_multigrid_level(int level) {
     if (level >= 0 && level < get_num_levels()) current_level = level;
@@ -378,6 +395,11 @@ class StatefulMultigridMG : public MultigridMG {
     if (total_num_levels > 1 && level_solve == 0) { std::cout << "[QMG-MG-SOLVE-ERROR]: Level solve for level " << level << " does not exist.\n"; return; }
     const long fine_size = mg->get_lattice(level)->get_size_cv_l();
     if (total_num_levels == 1) { copy_vector(lhs, rhs, fine_size); return; }   // :803-807
+    // ONE engine: configurations the lock-step batch engine implements (ORIGINAL or right-block-Jacobi Schur operators, MR
+    // smoothers, GCR coarse solves -- n13, n19, n22) run there as a batch of one system: same algorithm step for step, with the
+    // fixed-count smoothers' scalars on the device (batch.hpp).  Everything else (CGNE / CGNR smoothers, normal-equation
+    // coarsest solves, y-slab mode with its overlapped exchanges) continues below.
+    if (qmg_kcycle_via_batch(mg, lhs, rhs, size, verb)) return;
 
     Stencil2D* coarse_stencil = mg->get_stencil(level + 1);
     TransferMG* transfer = mg->get_transfer(level);

@@ -544,6 +544,50 @@ struct Stencil2D {
     qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
   }
 
+  // ONE system (number `system` of a batch `stride` apart) with an apply epilogue (include/qmg_hip.h: qmg_apply_epilogue): the finished site
+  // values become other_scale other + acc_scale acc and / or leave their MR dots in the thread's device slot -- instead of separate BLAS-1
+  // passes over the result.  Same choice of arrays and kernels as launch_set_batch.  false: this configuration is not served with an
+  // epilogue (y-slabs, 16-bit matrices, the nc = 1 / 4 kernels); nothing was launched and the caller runs the separate passes.
+  template <typename T>
+  bool launch_set_epi(unsigned pieces, complex<T>* lhs, complex<T>* rhs, QMGArraySet set, complex<double> s, complex<double> es, complex<double> ds,
+                      size_t stride, int system, const qmg_apply_epilogue& epi) {
+    static const bool wanted = !(getenv("QMG_APPLY_EPILOGUE") && atoi(getenv("QMG_APPLY_EPILOGUE")) == 0);
+    if (!wanted || qmg::slab().on) return false;
+    const bool f = sizeof(T) == sizeof(float);
+    const int dt = f ? QMG_C32 : QMG_C64;
+    qmg_stencil_desc d;
+    d.Lx = lat->get_dim_mu(0); d.Ly = lat->get_dim_mu(1); d.nc = lat->get_nc();
+    d.clover = 0; d.hopping = 0;
+    d.shift[0] = s.real(); d.shift[1] = s.imag();
+    d.eo_shift[0] = es.real(); d.eo_shift[1] = es.imag();
+    d.dof_shift[0] = ds.real(); d.dof_shift[1] = ds.imag();
+    const int nrhs = system + 1;
+    const unsigned mask = 1u << system;
+    auto served = [](int rc, const char* what) { if (rc == QMG_SUCCESS) return 1; if (rc == QMG_ERR_UNSUPPORTED) return 0; qmg::ok(rc, what); return -1; };
+    if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (!f || direct.gauge32)) {
+      const int r = served(qmg_wilson_apply_direct_epi(dt, &d, f ? direct.gauge32 : (void*)direct.gauge, d.Ly, 0, direct.w, lhs, rhs, 0, 0, pieces, nrhs, stride, 0, mask,
+                                                       &epi, qmg::current_stream()), "qmg_wilson_apply_direct_epi");
+      if (r) return true;   // (an error has been reported; falling back would only repeat it)
+    }
+    if (set == QMG_ARR_RBJ_HOPPING && rbj_direct_usable(0, rbjacobi_hopping_in_use(), pieces) && (!f || direct.gauge32)) {
+      const int r = served(qmg_wilson_hops_direct_epi(dt, &d, f ? direct.gauge32 : (void*)direct.gauge, d.Ly, 0, direct.w, direct.rbj_scale, lhs, rhs, 0, 0, pieces, nrhs,
+                                                      stride, 0, mask, &epi, qmg::current_stream()), "qmg_wilson_hops_direct_epi");
+      if (r) return true;
+    }
+    int mat32 = 0;
+    if (f) {
+      if (!f32.on || (f32.half_on && set != QMG_ARR_RBJ_CINV)) return false;
+      d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
+      d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+      mat32 = 1;
+    } else {
+      d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
+      d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
+      if (set == QMG_ARR_ORIGINAL && f32_matrices) { d.clover = clover32; d.hopping = hopping32; mat32 = 1; }
+    }
+    return served(qmg_stencil_apply_epi_t(dt, mat32, &d, lhs, rhs, pieces, stride, system, &epi, qmg::current_stream()), "qmg_stencil_apply_epi_t") != 0;
+  }
+
   // lhs_k = M rhs_k for the active systems of a lock-step batch (<= 16 vectors `stride` apart): one read of the matrices;
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
   void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {

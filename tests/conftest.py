@@ -25,7 +25,7 @@ def golden_dir():
 # y-slab extension last.  Files not listed keep their alphabetical place after the listed ones.
 _ORDER = [
     "test_abi_symbols", "test_oracle_known_answers", "test_oracle_krylov", "test_oracle_kcycle", "test_host_logic", "test_distributed_cpu",
-    "test_gpu_parity", "test_gpu_wilson_direct", "test_gpu_f32", "test_gpu_apply_norm", "test_gpu_reductions", "test_gpu_krylov", "test_gpu_u1",
+    "test_gpu_parity", "test_gpu_wilson_direct", "test_gpu_f32", "test_gpu_epilogue", "test_gpu_apply_norm", "test_gpu_reductions", "test_gpu_krylov", "test_gpu_u1",
     "test_gpu_kcycle", "test_gpu_batch", "test_gpu_fullsize", "test_gpu_slab",
 ]
 

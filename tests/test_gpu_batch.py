@@ -293,3 +293,60 @@ def test_batch_non_temporal_reads_change_no_bit(dtype):
         qmg.set_tuning("blas_nt_mb", 256)
     for u, v in zip(res[0], res[1]):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("nrhs,mask", [(1, 0b1), (5, 0b01101), (16, 0xFFFF)])
+@pytest.mark.parametrize("dtype", ["c64", "c32"])
+def test_mr_step_with_device_scalars_is_the_host_scalar_step(nrhs, mask, dtype):
+    """qmg_batch_mr_dots_t + qmg_batch_mr_update_t (the K-cycle's fixed-count smoother, scalars never leave the device) against the
+    host-scalar step of bminv_vector_minres_zero_guess built from the existing entry points: multidot of {r, p} against p, alpha =
+    omega conj(<r,p>) / <p,p> on the host, two caxpy.  Same reduction order and the same (omega pr) / pp: x and r BIT FOR BIT, in both
+    storage precisions; the dots in the device slot equal the multidot's; frozen systems untouched; the x_set form (x = alpha r) equals
+    the accumulate form on x = 0; <p,p> = 0 leaves a system as it is."""
+    dt = qmg.C64 if dtype == "c64" else qmg.C32
+    n, pad, omega = 3000, 8, 0.85
+    stride = n + pad
+    tohost = (lambda d: d.to_host()) if dtype == "c64" else (lambda d: d.to_host())
+    mk = (lambda a: D(a)) if dtype == "c64" else (lambda a: qmg.DeviceArray.from_host(np.ascontiguousarray(a, dtype=np.complex64)))
+    x0, r0, p0 = cs.gaussian_cvec(stride * nrhs, 1), cs.gaussian_cvec(stride * nrhs, 2), cs.gaussian_cvec(stride * nrhs, 3)
+    if dtype == "c32":
+        x0, r0, p0 = (v.astype(np.complex64) for v in (x0, r0, p0))
+    act = active(mask, nrhs)
+    # host-scalar reference through the existing batched entry points
+    dr, dp = mk(r0), mk(p0)
+    d2 = qmg.batch_multidot_t(dt, [dr, dp], dp, n, nrhs, stride, mask)
+    alpha = np.zeros(nrhs, dtype=np.complex128)
+    for k in act:
+        alpha[k] = omega * np.conj(d2[k, 0]) / d2[k, 1].real
+    wx, wr = mk(x0), mk(r0)
+    qmg.batch_blas_t(dt, qmg.BOP_CAXPY, wx, n, nrhs, stride, mask, a=alpha, x=dr)
+    qmg.batch_blas_t(dt, qmg.BOP_CAXPY, wr, n, nrhs, stride, mask, a=-alpha, x=dp)
+    # device-scalar step
+    gx, gr = mk(x0), mk(r0)
+    qmg.batch_mr_dots(dt, gr, dp, n, nrhs, stride, mask)
+    slot = qmg.batch_mr_read_dots(nrhs)
+    for k in act:
+        assert slot[k, 0] == d2[k, 0].real and slot[k, 1] == -d2[k, 0].imag and slot[k, 2] == d2[k, 1].real, k   # <p,r> = conj(<r,p>)
+    qmg.batch_mr_update(dt, omega, gx, gr, gr, dp, False, n, nrhs, stride, mask)
+    assert np.array_equal(gx.to_host(), wx.to_host()) and np.array_equal(gr.to_host(), wr.to_host())
+    for k in range(nrhs):
+        if k not in act:
+            assert np.array_equal(gx.to_host()[k * stride:(k + 1) * stride], x0[k * stride:(k + 1) * stride])
+    # x_set: x = alpha r_in on whatever x held; r_out a different vector; r_out = NULL leaves r alone
+    gx2, gr2, gout = mk(x0), mk(r0), mk(np.zeros_like(r0))
+    qmg.batch_mr_dots(dt, gr2, dp, n, nrhs, stride, mask)
+    qmg.batch_mr_update(dt, omega, gx2, gr2, gout, dp, True, n, nrhs, stride, mask)
+    zx = mk(np.zeros_like(x0))
+    qmg.batch_blas_t(dt, qmg.BOP_CAXPY, zx, n, nrhs, stride, mask, a=alpha, x=dr)
+    for k in act:
+        sl = slice(k * stride, k * stride + n)
+        assert np.array_equal(gx2.to_host()[sl], zx.to_host()[sl]) and np.array_equal(gout.to_host()[sl], wr.to_host()[sl])
+    assert np.array_equal(gr2.to_host(), r0)
+    qmg.batch_mr_update(dt, omega, gx2, gr2, None, dp, True, n, nrhs, stride, mask)
+    assert np.array_equal(gr2.to_host(), r0)
+    # breakdown: p = 0 -> <p,p> = 0 -> alpha = 0: x and r unchanged (accumulate form), x = 0 (x_set form)
+    zp = mk(np.zeros_like(p0))
+    gx3, gr3 = mk(x0), mk(r0)
+    qmg.batch_mr_dots(dt, gr3, zp, n, nrhs, stride, mask)
+    qmg.batch_mr_update(dt, omega, gx3, gr3, gr3, zp, False, n, nrhs, stride, mask)
+    assert np.array_equal(gx3.to_host(), x0) and np.array_equal(gr3.to_host(), r0)

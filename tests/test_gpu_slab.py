@@ -27,6 +27,14 @@ def _device():
     qmg.sync()
 
 
+@pytest.fixture(autouse=True)
+def _fp64_coarse_storage(monkeypatch):
+    """The single-domain drivers store the Galerkin matrices of their preconditioner levels as complex<float> by default; slab mode
+    streams the fp64 arrays (multigrid.hpp: coarse_f32_wanted).  These tests compare the two runs digit by digit, so the children
+    of this module run with fp64 coarse storage on both sides."""
+    monkeypatch.setenv("QMG_COARSE_F32", "0")
+
+
 def rows(a, Ly, per_row, y0, n):
     """rows y0 .. y0+n-1 of every (array, parity) plane of an even-odd array: a = [planes][2][Ly][per_row]"""
     planes = a.size // (2 * Ly * per_row)
