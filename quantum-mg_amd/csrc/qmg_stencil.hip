@@ -79,28 +79,26 @@ template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i
 template <bool V32> __device__ __forceinline__ void stv(void* base, long i, cplx v) { if (V32) stc<float>(base, i, v); else stc<double>(base, i, v); }
 
 // the epilogue of one output element (qmg_common.h: Epilogue): returns the value to store, accumulates the MR dots of the value AS STORED
+// ov / r: the element's `other` / `dotv` values, loaded by the caller at the START of the row (a load issued here, after the tile loop,
+// would add a full memory latency to every block)
 template <bool V32>
-__device__ __forceinline__ cplx epilogue_value(const Epilogue& e, long o, cplx t, double (&d)[3]) {
-  if (e.other) {
-    const cplx ov = ldv<V32>(e.other, o);
-    t = cmake(fma(e.other_scale, ov.x, e.acc_scale * t.x), fma(e.other_scale, ov.y, e.acc_scale * t.y));
-  } else if (e.acc_scale != 1.0) t = cmake(e.acc_scale * t.x, e.acc_scale * t.y);
+__device__ __forceinline__ cplx epilogue_value(const Epilogue& e, cplx ov, cplx r, cplx t, double (&d)[3]) {
+  if (e.other) t = cmake(fma(e.other_scale, ov.x, e.acc_scale * t.x), fma(e.other_scale, ov.y, e.acc_scale * t.y));
+  else if (e.acc_scale != 1.0) t = cmake(e.acc_scale * t.x, e.acc_scale * t.y);
   if (e.dotv) {
     const cplx sv = V32 ? cmake((double)(float)t.x, (double)(float)t.y) : t;
-    const cplx r = ldv<V32>(e.dotv, o);
     d[0] = fma(r.x, sv.x, d[0]); d[0] = fma(r.y, sv.y, d[0]);      // conj(r) out
     d[1] = fma(r.x, sv.y, d[1]); d[1] = fma(-r.y, sv.x, d[1]);
     d[2] = fma(sv.x, sv.x, d[2]); d[2] = fma(sv.y, sv.y, d[2]);
   }
   return t;
 }
-// end of a ROW of a kernel with an epilogue: one partial per (row, block, wavefront), [slot][4] (system slot 0); every lane of the block calls it.
-// Per row, not per launch, so that the dot accumulators are not carried around the row loop (7 VGPRs and, for several tile shapes, a
-// wavefront of occupancy in the launches that have no epilogue at all).
-__device__ __forceinline__ void epilogue_store_partials(const Epilogue& e, double (&d)[3], int row) {
+// end of a kernel with an epilogue: one partial per wavefront of the launch, [slot][4] (system slot 0); every lane of the block calls it
+// (the launchers cap grid.y for these launches, so that the one-block second stage sums a few thousand partials, not one per row)
+__device__ __forceinline__ void epilogue_store_partials(const Epilogue& e, double (&d)[3]) {
   const double s0 = wave_sum(d[0]), s1 = wave_sum(d[1]), s2 = wave_sum(d[2]);
   if ((threadIdx.x & (WAVE - 1)) == 0) {
-    const long w = ((long)row * gridDim.x + blockIdx.x) * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    const long w = ((long)blockIdx.y * gridDim.x + blockIdx.x) * (BLOCK / WAVE) + threadIdx.x / WAVE;
     double* p = e.part + w * 4;
     p[0] = s0; p[1] = s1; p[2] = s2; p[3] = 0.0;
   }
@@ -547,9 +545,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
   const int j0 = blockIdx.x * L.S;
   const int nsite = (a.hr - j0 < L.S) ? a.hr - j0 : L.S;    // ragged last tile
   const long nc2 = (long)nc * nc;
+  double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue (EPI instantiations: one system per launch)
 
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
-    double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue over this row (one system per launch)
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
     const int y = (a.par_count == 2) ? (row >> 1) : row;
     const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
@@ -563,6 +561,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
     const int s = (y + p) & 1;
     const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
     const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+    cplx e_ov = cmake(0.0, 0.0), e_dv = cmake(0.0, 0.0);   // the epilogue's operands of this thread's output element, requested up front
+    if (EPI && h == 0 && s_of < nsite) {
+      const long o = rhs_offset(a, 0) + (site0 + s_of) * nc + r_of;
+      if (a.epi.other) e_ov = ldv<V32>(a.epi.other, o);
+      if (a.epi.dotv) e_dv = (a.epi.dotv == a.epi.other) ? e_ov : ldv<V32>(a.epi.dotv, o);
+    }
 
     for (int k0 = 0; k0 < a.nrhs; k0 += KR) {
       const int nk = (a.nrhs - k0 < KR) ? a.nrhs - k0 : KR;
@@ -702,13 +706,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
           const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
           if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
-          if (EPI) t = epilogue_value<V32>(a.epi, o, t, edots);
+          if (EPI) t = epilogue_value<V32>(a.epi, e_ov, e_dv, t, edots);
           stv<V32>(a.lhs, o, t);
         }
       }
     }
-    if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots, row);
   }
+  if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots);
 }
 
 // Kernel B32 (opt-in complex<float> matrix storage, even nc): kernel B with the tile kept in fp32 end to end -- 16-B
@@ -737,9 +741,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
   const int j0 = blockIdx.x * L.S;
   const int nsite = (a.hr - j0 < L.S) ? a.hr - j0 : L.S;    // ragged last tile
   const long nc2 = (long)nc * nc;
+  double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue (EPI instantiations: one system per launch)
 
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
-    double edots[3] = {0.0, 0.0, 0.0};   // MR dots of the epilogue over this row (one system per launch)
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
     const int y = (a.par_count == 2) ? (row >> 1) : row;
     const bool do_clover = a.clover && ((a.pieces >> p) & 1u);
@@ -753,6 +757,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
     const int s = (y + p) & 1;
     const int yp = (y + 1 == a.Ly) ? 0 : y + 1;
     const int ym = (y == 0) ? a.Ly - 1 : y - 1;
+    cplx e_ov = cmake(0.0, 0.0), e_dv = cmake(0.0, 0.0);   // the epilogue's operands of this thread's output element, requested up front
+    if (EPI && h == 0 && s_of < nsite) {
+      const long o = rhs_offset(a, 0) + (site0 + s_of) * nc + r_of;
+      if (a.epi.other) e_ov = ldv<V32>(a.epi.other, o);
+      if (a.epi.dotv) e_dv = (a.epi.dotv == a.epi.other) ? e_ov : ldv<V32>(a.epi.dotv, o);
+    }
 
     for (int k0 = 0; k0 < a.nrhs; k0 += KR) {
       const int nk = (a.nrhs - k0 < KR) ? a.nrhs - k0 : KR;
@@ -858,13 +868,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           for (int hh = 1; hh < L.H; hh++) t = cadd(t, red[(size_t)hh * rows + sr]);
           const long o = rhs_offset(a, k0 + kk) + (site0 + s_of) * nc + r_of;
           if (!do_zero) t = cadd(ldv<V32>(a.lhs, o), t);
-          if (EPI) t = epilogue_value<V32>(a.epi, o, t, edots);
+          if (EPI) t = epilogue_value<V32>(a.epi, e_ov, e_dv, t, edots);
           stv<V32>(a.lhs, o, t);
         }
       }
     }
-    if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots, row);
   }
+  if (EPI && a.epi.dotv) epilogue_store_partials(a.epi, edots);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1408,11 +1418,13 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1, 1);
 }
 
-// the epilogue's dot partials: one slot per (row, block, wavefront) (system slot 0), summed by mr_epilogue_finish into the thread's MR slot
+// the epilogue's dot partials: one slot per wavefront of the launch (system slot 0), summed by mr_epilogue_finish into the thread's MR slot
 #define QMG_EPI_BEGIN(GX, GY)                                                                   \
   long epi_npart = 0;                                                                           \
   if (a.epi.on && a.epi.dotv) {                                                                 \
-    epi_npart = (long)(GX) * (long)(GY) * (BLOCK / WAVE);                                       \
+    const unsigned epi_cap = (GX) >= 2048u ? 1u : 2048u / (GX);   /* a few thousand partials for the one-block second stage: blocks walk rows */ \
+    if (grid.y > epi_cap) grid.y = epi_cap;                                                     \
+    epi_npart = (long)(GX) * (long)grid.y * (BLOCK / WAVE);                                       \
     a.epi.part = mr_epilogue_begin(1, epi_npart);                                               \
     a.epi.npart = epi_npart;                                                                    \
     if (!a.epi.part) return QMG_ERR_HIP;                                                        \
@@ -1633,7 +1645,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       if (smem <= 64 * 1024) {
         const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
         dim3 grid(gx, gy), block(BLOCK);
-        QMG_EPI_BEGIN(gx, a.nrows)
+        QMG_EPI_BEGIN(gx, gy)
 #define QMG_G32_CASE2(PP, KR) { if (a.vec32) k_stencil_gen32<PP, KR, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, KR, false><<<grid, block, smem, st>>>(a, nc, L); }
 #define QMG_G32_EPI(PP) { if (a.vec32) k_stencil_gen32<PP, 1, true, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, 1, false, true><<<grid, block, smem, st>>>(a, nc, L); }
 #define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else if (a.epi.on) { QMG_G32_EPI(PP) } else { QMG_G32_CASE2(PP, 1) } } break;
@@ -1659,7 +1671,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (smem > 160 * 1024) return QMG_ERR_UNSUPPORTED;
   const unsigned gx = (unsigned)((a.hr + L.S - 1) / L.S);
   dim3 grid(gx, gy), block(BLOCK);
-  QMG_EPI_BEGIN(gx, a.nrows)
+  QMG_EPI_BEGIN(gx, gy)
 #define QMG_GEN_CASE3(PT, M32, KR, V32)                                                                 \
     {                                                                                                   \
       if (smem > 64 * 1024)                                                                             \

@@ -99,17 +99,27 @@ __device__ __forceinline__ HopCol<R> hop_col(int d, int c, R ux, R uy, R hw, R s
   return o;
 }
 
+// this lane's 16-byte chunk of an epilogue vector at byte offset boff from its base (or zeros when the vector is absent)
+__device__ __forceinline__ w4f epi_chunk(const void* vec, long boff) {
+  w4f z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f;
+  return vec ? *reinterpret_cast<const w4f*>(reinterpret_cast<const char*>(vec) + boff) : z;
+}
+
 // One site's (fp64: one site's column c0) result from its five right-hand-side chunks xr = {+x, +y, -x, -y, own} and its four
 // links (backward ones already conjugated), then the store.  The order of operations is kernel S's (qmg_site.hip).
 // SHAPE 1: clover + hops (+ shift); 2: hops; 3: hops scaled by a.hop_scale.
 // live = false: a padding lane past the end of the half row (it computed a copy of the last site so that every lane of the wavefront
-// stays active for the epilogue's wavefront sums): nothing is stored, nothing is added to the dots.  boff: byte offset of this lane's
-// chunk from the base of lhs (system offset included) -- where the epilogue's `other` / `dotv` chunks live in their vectors.
-// EPI is a compile-time switch: the launches without an epilogue keep their register count (a run-time branch cost pair2<float> 34 VGPRs and a
-// wavefront of occupancy).
-template <typename T, int SHAPE, bool EPI>
+// stays active for the epilogue's wavefront sums): nothing is stored, nothing is added to the dots.  ec: this lane's chunk of the
+// epilogue's vector, loaded by the caller IN ITS LOAD PHASE (a load issued here, after the arithmetic, would add one full memory
+// latency to every wavefront: measured +4 % on the whole K-cycle).
+// EPI is a compile-time mode: the launches without an epilogue keep their register count (a run-time branch cost pair2<float> 34 VGPRs and a
+// wavefront of occupancy), and each mode pays only for what it loads:
+//   0 none | 1 dots against the right-hand side's own-site chunk (MR on the full operator: p = A r, <p,r>: nothing extra is loaded) |
+//   2 out = os other + as acc | 3 the same, and dots against `other` (the Schur complement's r_e - D_eo t with MR dots against r_e) |
+//   4 dots against a separate vector.  Modes 2-4 load ONE extra chunk per site (`ec`).
+template <typename T, int SHAPE, int EPI>
 __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4], const T (&ly)[4], T hw, T cw, bool do_shift, bool do_zero, int p, int c0,
-                                            const WilsonArgs& a, gchar* dst_chunk, long boff, bool live, double (&ed)[3]) {
+                                            const WilsonArgs& a, gchar* dst_chunk, const w4f& ec, bool live, double (&ed)[3]) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int NCOL = F64 ? 1 : 2;
   typedef T R;
@@ -156,12 +166,12 @@ __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4]
     __attribute__((address_space(1))) w2d* dst = (__attribute__((address_space(1))) w2d*)dst_chunk;
     if (!do_zero) { const w2d pv = *dst; o.x += pv.x; o.y += pv.y; }
     if (EPI) {
-      if (a.epi.other) {
-        const w2d ov = *reinterpret_cast<const w2d*>(reinterpret_cast<const char*>(a.epi.other) + boff);
+      if (EPI == 2 || EPI == 3) {
+        const w2d ov = __builtin_bit_cast(w2d, ec);
         o.x = fma(a.epi.other_scale, ov.x, a.epi.acc_scale * o.x); o.y = fma(a.epi.other_scale, ov.y, a.epi.acc_scale * o.y);
       } else if (a.epi.acc_scale != 1.0) { o.x *= a.epi.acc_scale; o.y *= a.epi.acc_scale; }
-      if (a.epi.dotv && live) {
-        const w2d r = *reinterpret_cast<const w2d*>(reinterpret_cast<const char*>(a.epi.dotv) + boff);
+      if (EPI != 2 && live) {
+        const w2d r = __builtin_bit_cast(w2d, EPI == 1 ? xr[4] : ec);
         ed[0] = fma(r.x, o.x, ed[0]); ed[0] = fma(r.y, o.y, ed[0]);
         ed[1] = fma(r.x, o.y, ed[1]); ed[1] = fma(-r.y, o.x, ed[1]);
         ed[2] = fma(o.x, o.x, ed[2]); ed[2] = fma(o.y, o.y, ed[2]);
@@ -175,13 +185,13 @@ __device__ __forceinline__ void wilson_site(const w4f (&xr)[5], const T (&lx)[4]
     __attribute__((address_space(1))) w4f* dst = (__attribute__((address_space(1))) w4f*)dst_chunk;
     if (!do_zero) { const w4f pv = *dst; o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w; }
     if (EPI) {
-      if (a.epi.other) {
-        const w4f ov = *reinterpret_cast<const w4f*>(reinterpret_cast<const char*>(a.epi.other) + boff);
+      if (EPI == 2 || EPI == 3) {
+        const w4f ov = ec;
         const float os = (float)a.epi.other_scale, as = (float)a.epi.acc_scale;
         o.x = fmaf(os, ov.x, as * o.x); o.y = fmaf(os, ov.y, as * o.y); o.z = fmaf(os, ov.z, as * o.z); o.w = fmaf(os, ov.w, as * o.w);
       } else if (a.epi.acc_scale != 1.0) { const float as = (float)a.epi.acc_scale; o.x *= as; o.y *= as; o.z *= as; o.w *= as; }
-      if (a.epi.dotv && live) {   // both components of the site, accumulated in fp64 from the values as stored
-        const w4f r = *reinterpret_cast<const w4f*>(reinterpret_cast<const char*>(a.epi.dotv) + boff);
+      if (EPI != 2 && live) {   // both components of the site, accumulated in fp64 from the values as stored
+        const w4f r = (EPI == 1) ? xr[4] : ec;
         const double r0x = r.x, r0y = r.y, r1x = r.z, r1y = r.w, o0x = o.x, o0y = o.y, o1x = o.z, o1y = o.w;
         ed[0] = fma(r0x, o0x, ed[0]); ed[0] = fma(r0y, o0y, ed[0]); ed[0] = fma(r1x, o1x, ed[0]); ed[0] = fma(r1y, o1y, ed[0]);
         ed[1] = fma(r0x, o0y, ed[1]); ed[1] = fma(-r0y, o0x, ed[1]); ed[1] = fma(r1x, o1y, ed[1]); ed[1] = fma(-r1y, o1x, ed[1]);
@@ -204,7 +214,7 @@ __device__ __forceinline__ void wilson_store_partials(const WilsonArgs& a, doubl
 
 // T = storage scalar (double: 2 lanes per site; float: 1 lane per site).  SHAPE 1: clover + hops (+ shift); 2: hops only;
 // 3: hops only, entries scaled (right-block-Jacobi).
-template <typename T, int SHAPE, bool ZERO, bool BATCH, bool EPI = false>
+template <typename T, int SHAPE, bool ZERO, bool BATCH, int EPI = 0>
 __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
@@ -264,6 +274,8 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
       if (SHAPE == 1 || do_shift) xr[4] = gld<w4f>(uni(x + row_own), off_j);
     };
     load_x(0);
+    w4f e_c = xr[0];                               // the epilogue's chunk of this site (modes 2-4; a placeholder otherwise)
+    if (EPI >= 2) e_c = epi_chunk(EPI == 4 ? a.epi.dotv : a.epi.other, (long)a.ridx[0] * sys_bytes + row_own + off_j);
     R lx[4], ly[4];                                // links per direction, conjugated for the backward ones
     if (F64) {
       const w2d u0 = gld_nt<w2d>(g_own_x, goff_j);
@@ -286,17 +298,17 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_direct(const WilsonArgs a) {
     for (int k = 0; k < nsys; k++) {
       if (BATCH && k > 0) { load_x(k); __builtin_amdgcn_sched_barrier(0); }
       char* out = reinterpret_cast<char*>(a.lhs) + (long)a.ridx[k] * sys_bytes;
-      wilson_site<T, SHAPE, EPI>(xr, lx, ly, hw, cw, do_shift, do_zero, p, c0, a, uni(out + row_own) + off_j, (long)a.ridx[k] * sys_bytes + row_own + off_j, live, ed);
+      wilson_site<T, SHAPE, EPI>(xr, lx, ly, hw, cw, do_shift, do_zero, p, c0, a, uni(out + row_own) + off_j, e_c, live, ed);
     }
   }
-  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
+  if (EPI && EPI != 2) wilson_store_partials(a, ed);
 }
 
 // Kernel W2: BOTH parities of column j on row y per lane group -- the full operator (clover + all hops on both parities).
 // Kernel W is not HBM-bound but in-flight-bound (3 KB of HBM requests per wavefront); a pair shares what the two sites
 // have in common -- each site's own chunk is an x-neighbour of the other, one back link is the other's own link: 15 loads
 // per pair instead of 18 -- and puts twice the HBM bytes of a wavefront in flight.  Per-site arithmetic = wilson_site.
-template <typename T, bool ZERO, bool BATCH, bool EPI = false>
+template <typename T, bool ZERO, bool BATCH, int EPI = 0>
 __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
@@ -344,6 +356,11 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
       upO = gld<w4f>(bE_up, off_j); dnO = gld<w4f>(bE_dn, off_j);
     };
     load_x(0);
+    w4f ecE = ownE, ecO = ownO;   // the epilogue's chunks of the two sites (modes 2-4)
+    if (EPI >= 2) {
+      const void* ev = (EPI == 4) ? a.epi.dotv : a.epi.other;
+      ecE = epi_chunk(ev, (long)a.ridx[0] * sys_bytes + rowE + off_j); ecO = epi_chunk(ev, (long)a.ridx[0] * sys_bytes + rowO + off_j);
+    }
     // links (global lattice): own of both sites, the one back-x link that is not the partner's own, two back-y links
     const int gy = a.gy0 + y;
     const int gym = (gy == 0) ? a.gLy - 1 : gy - 1;
@@ -369,24 +386,24 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair(const WilsonArgs a) {
         const LK bxE = sE ? uxO : ubx;                   // Ux at the even site's -x neighbour (an odd site at jmE = j + sE - 1)
         const R lxE[4] = {(R)uxE.x, (R)uyE.x, (R)bxE.x, (R)ubyE.x}, lyE[4] = {(R)uxE.y, (R)uyE.y, -(R)bxE.y, -(R)ubyE.y};
         const w4f xrE[5] = {sE ? othO : ownO, upE, sE ? ownO : othO, dnE, ownE};
-        wilson_site<T, 1, EPI>(xrE, lxE, lyE, hw, cw, shE, zE, 0, c0, a, uni(out + rowE) + off_j, (long)a.ridx[k] * sys_bytes + rowE + off_j, live, ed);
+        wilson_site<T, 1, EPI>(xrE, lxE, lyE, hw, cw, shE, zE, 0, c0, a, uni(out + rowE) + off_j, ecE, live, ed);
       }
       {
         const LK bxO = sE ? ubx : uxE;                   // Ux at the odd site's -x neighbour (an even site at jmO = j - sE)
         const R lxO[4] = {(R)uxO.x, (R)uyO.x, (R)bxO.x, (R)ubyO.x}, lyO[4] = {(R)uxO.y, (R)uyO.y, -(R)bxO.y, -(R)ubyO.y};
         const w4f xrO[5] = {sE ? ownE : othE, upO, sE ? othE : ownE, dnO, ownO};
-        wilson_site<T, 1, EPI>(xrO, lxO, lyO, hw, cw, shO, zO, 1, c0, a, uni(out + rowO) + off_j, (long)a.ridx[k] * sys_bytes + rowO + off_j, live, ed);
+        wilson_site<T, 1, EPI>(xrO, lxO, lyO, hw, cw, shO, zO, 1, c0, a, uni(out + rowO) + off_j, ecO, live, ed);
       }
     }
   }
-  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
+  if (EPI && EPI != 2) wilson_store_partials(a, ed);
 }
 
 // Kernel W2 on TWO consecutive rows per lane group (one system): rows y and y + 1 are each other's +-y neighbours and back-y
 // links, so the four sites take 12 + 12 loads instead of 2 x (8 + 7), and -- what matters for a kernel that is bound by the
 // bytes a wavefront has in flight -- every wavefront requests 12 KB of HBM data instead of 6 (at 3 resident wavefronts per SIMD
 // instead of 4).  Per-site arithmetic = wilson_site, so the results are the one-row kernel's bit for bit.
-template <typename T, bool ZERO, bool EPI = false>
+template <typename T, bool ZERO, int EPI = 0>
 __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
   constexpr bool F64 = sizeof(T) == 8;
   constexpr int LPS = F64 ? 2 : 1;
@@ -431,6 +448,12 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
     const w4f othOB = gld<w4f>(bOB, sB ? off_r : off_l), othEB = gld<w4f>(bEB, sB ? off_l : off_r);
     const w4f dnEA = gld<w4f>(bO_dn, off_j), dnOA = gld<w4f>(bE_dn, off_j);      // row y - 1: odd site under the even one, even under odd
     const w4f upEB = gld<w4f>(bO_up, off_j), upOB = gld<w4f>(bE_up, off_j);      // row y + 2
+    w4f ecEA = ownEA, ecOA = ownOA, ecEB = ownEB, ecOB = ownOB;   // epilogue chunks (modes 2-4)
+    if (EPI >= 2) {
+      const void* ev = (EPI == 4) ? a.epi.dotv : a.epi.other;
+      ecEA = epi_chunk(ev, off + rowEA + off_j); ecOA = epi_chunk(ev, off + rowOA + off_j);
+      ecEB = epi_chunk(ev, off + rowEB + off_j); ecOB = epi_chunk(ev, off + rowOB + off_j);
+    }
     const int gy = a.gy0 + y;
     const int gym = (gy == 0) ? a.gLy - 1 : gy - 1;
     const long gvol = 2 * a.ghalf_vol;
@@ -455,35 +478,49 @@ __global__ __launch_bounds__(BLOCK) void k_wilson_pair2(const WilsonArgs a) {
       const LK bx = sA ? uxOA : ubxA;
       const R lx[4] = {(R)uxEA.x, (R)uyEA.x, (R)bx.x, (R)ubyEA.x}, ly[4] = {(R)uxEA.y, (R)uyEA.y, -(R)bx.y, -(R)ubyEA.y};
       const w4f xr[5] = {sA ? othOA : ownOA, ownOB, sA ? ownOA : othOA, dnEA, ownEA};
-      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEA) + off_j, off + rowEA + off_j, live, ed);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEA) + off_j, ecEA, live, ed);
     }
     {   // row A, odd site
       const LK bx = sA ? ubxA : uxEA;
       const R lx[4] = {(R)uxOA.x, (R)uyOA.x, (R)bx.x, (R)ubyOA.x}, ly[4] = {(R)uxOA.y, (R)uyOA.y, -(R)bx.y, -(R)ubyOA.y};
       const w4f xr[5] = {sA ? ownEA : othEA, ownEB, sA ? othEA : ownEA, dnOA, ownOA};
-      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOA) + off_j, off + rowOA + off_j, live, ed);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOA) + off_j, ecOA, live, ed);
     }
     {   // row B, even site: -y = the odd site of row A, back-y link = that site's Uy
       const LK bx = sB ? uxOB : ubxB;
       const R lx[4] = {(R)uxEB.x, (R)uyEB.x, (R)bx.x, (R)uyOA.x}, ly[4] = {(R)uxEB.y, (R)uyEB.y, -(R)bx.y, -(R)uyOA.y};
       const w4f xr[5] = {sB ? othOB : ownOB, upEB, sB ? ownOB : othOB, ownOA, ownEB};
-      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEB) + off_j, off + rowEB + off_j, live, ed);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shE, zE, 0, c0, a, uni(out + rowEB) + off_j, ecEB, live, ed);
     }
     {   // row B, odd site
       const LK bx = sB ? ubxB : uxEB;
       const R lx[4] = {(R)uxOB.x, (R)uyOB.x, (R)bx.x, (R)uyEA.x}, ly[4] = {(R)uxOB.y, (R)uyOB.y, -(R)bx.y, -(R)uyEA.y};
       const w4f xr[5] = {sB ? ownEB : othEB, upOB, sB ? othEB : ownEB, ownEA, ownOB};
-      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOB) + off_j, off + rowOB + off_j, live, ed);
+      wilson_site<T, 1, EPI>(xr, lx, ly, hw, cw, shO, zO, 1, c0, a, uni(out + rowOB) + off_j, ecOB, live, ed);
     }
   }
-  if (EPI && a.epi.dotv) wilson_store_partials(a, ed);
+  if (EPI && EPI != 2) wilson_store_partials(a, ed);
 }
 
+// one system, overwrite, with the epilogue in mode `m` (1-4; mode 1 needs the own-site chunk: SHAPE 1)
+template <typename T, int SHAPE>
+static void launch_wilson_epi_s(const WilsonArgs& a, int m, dim3 grid, hipStream_t st) {
+  if (m == 1) k_wilson_direct<T, SHAPE, true, false, (SHAPE == 1 ? 1 : 4)><<<grid, BLOCK, 0, st>>>(a);
+  else if (m == 2) k_wilson_direct<T, SHAPE, true, false, 2><<<grid, BLOCK, 0, st>>>(a);
+  else if (m == 3) k_wilson_direct<T, SHAPE, true, false, 3><<<grid, BLOCK, 0, st>>>(a);
+  else k_wilson_direct<T, SHAPE, true, false, 4><<<grid, BLOCK, 0, st>>>(a);
+}
 template <typename T>
-static void launch_wilson_epi(const WilsonArgs& a, int shape, dim3 grid, hipStream_t st) {   // one system, overwrite, with the epilogue
-  if (shape == 1) k_wilson_direct<T, 1, true, false, true><<<grid, BLOCK, 0, st>>>(a);
-  else if (shape == 3) k_wilson_direct<T, 3, true, false, true><<<grid, BLOCK, 0, st>>>(a);
-  else k_wilson_direct<T, 2, true, false, true><<<grid, BLOCK, 0, st>>>(a);
+static void launch_wilson_epi(const WilsonArgs& a, int shape, int m, dim3 grid, hipStream_t st) {
+  if (shape == 1) launch_wilson_epi_s<T, 1>(a, m, grid, st);
+  else if (shape == 3) launch_wilson_epi_s<T, 3>(a, m, grid, st);
+  else launch_wilson_epi_s<T, 2>(a, m, grid, st);
+}
+template <typename T>
+static void launch_wilson_pair_epi(const WilsonArgs& a, int m, bool two_rows, dim3 grid, hipStream_t st) {
+#define QMG_WP(M) { if (two_rows) k_wilson_pair2<T, true, M><<<grid, BLOCK, 0, st>>>(a); else k_wilson_pair<T, true, false, M><<<grid, BLOCK, 0, st>>>(a); }
+  if (m == 1) QMG_WP(1) else if (m == 2) QMG_WP(2) else if (m == 3) QMG_WP(3) else QMG_WP(4)
+#undef QMG_WP
 }
 
 template <typename T, bool BATCH>
@@ -574,6 +611,7 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
     if (epi->other == lhs || epi->dotv == lhs) return QMG_ERR_INVALID;
     a.epi.on = 1;
     a.epi.other = epi->other; a.epi.other_scale = epi->other_scale; a.epi.acc_scale = epi->acc_scale; a.epi.dotv = epi->dotv;
+    if (epi->other && epi->dotv && epi->other != epi->dotv) return QMG_ERR_UNSUPPORTED;   // two different extra vectors: the separate passes
   }
   for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
   const unsigned even_bits = QMG_P_CLOVER_E | QMG_P_EO | QMG_P_SHIFT_E | QMG_P_ZERO_E;
@@ -608,6 +646,18 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
   hipStream_t st = as_stream(stream);
   // the epilogue's dot partials: one per wavefront of the launch that is chosen below
   long epi_npart = 0;
+  // epilogue mode (wilson_site): 1 dots against the right-hand side (own-site chunk; needs SHAPE 1, else the vector is loaded: mode 4),
+  // 2 combination only, 3 combination + dots against the same vector, 4 dots against a separate vector
+  int emode = 0;
+  if (a.epi.on) {
+    if (!a.epi.other && !a.epi.dotv) emode = 2;                       // a pure scaling of the result (other_scale is moot): served by mode 2 with no vector
+    else if (a.epi.other && !a.epi.dotv) emode = 2;
+    else if (a.epi.other) emode = 3;
+    else emode = (a.epi.dotv == rhs && shape == 1) ? 1 : 4;
+  }
+  // launches with the MR dots keep the number of partials (one per wavefront) small enough for the one-block second stage: the blocks
+  // walk several rows each (every kernel W form has the row loop; capping grid.y costs nothing)
+  auto epi_cap = [&](dim3& g) { if (a.epi.on && a.epi.dotv) { const unsigned cap = g.x >= 2048u ? 1u : 2048u / g.x; if (g.y > cap) g.y = cap; } };
   auto epi_begin = [&](dim3 g) -> bool {
     if (!(a.epi.on && a.epi.dotv)) return true;
     epi_npart = (long)g.x * (long)g.y * (BLOCK / WAVE);
@@ -620,12 +670,14 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
     const unsigned char id0 = (unsigned char)a.ridx[0];
     return mr_epilogue_finish(&id0, 1, epi_npart, st);
   };
-  if (shape == 1 && a.par_count == 2 && g_wilson_pair >= 2 && a.nrhs == 1 && !a.boundary_only && a.y_count % 2 == 0) {
+  // (an epilogue that loads a vector -- modes 2-4 -- would take the two-row form to 170-178 VGPRs, two wavefronts per SIMD: those go through the one-row form)
+  if (shape == 1 && a.par_count == 2 && g_wilson_pair >= 2 && a.nrhs == 1 && !a.boundary_only && a.y_count % 2 == 0 && emode <= 1) {
     // one system, an even run of consecutive rows: kernel W2 on two rows per lane group
     const int ny = a.y_count / 2;   // (capping grid.y -- a row-pair loop per block -- changes nothing: 0.29-0.31 ms at every cap)
     dim3 gridp(grid.x, ny > 65535 ? 65535u : (unsigned)ny);
+    epi_cap(gridp);
     if (!epi_begin(gridp)) return QMG_ERR_HIP;
-    if (a.epi.on) { if (dtype == QMG_C64) k_wilson_pair2<double, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<float, true, true><<<gridp, BLOCK, 0, st>>>(a); }
+    if (a.epi.on) { if (dtype == QMG_C64) launch_wilson_pair_epi<double>(a, emode, true, gridp, st); else launch_wilson_pair_epi<float>(a, emode, true, gridp, st); }
     else if (dtype == QMG_C64) { if (zero) k_wilson_pair2<double, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<double, false><<<gridp, BLOCK, 0, st>>>(a); }
     else { if (zero) k_wilson_pair2<float, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair2<float, false><<<gridp, BLOCK, 0, st>>>(a); }
     QMG_LAUNCH_CHECK();
@@ -633,8 +685,9 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
   }
   if (shape == 1 && a.par_count == 2 && g_wilson_pair) {   // the full operator: both parities of a column per lane group (kernel W2)
     dim3 gridp(grid.x, a.y_count > 65535 ? 65535u : (unsigned)a.y_count);
+    epi_cap(gridp);
     if (!epi_begin(gridp)) return QMG_ERR_HIP;
-    if (a.epi.on) { if (dtype == QMG_C64) k_wilson_pair<double, true, false, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<float, true, false, true><<<gridp, BLOCK, 0, st>>>(a); }
+    if (a.epi.on) { if (dtype == QMG_C64) launch_wilson_pair_epi<double>(a, emode, false, gridp, st); else launch_wilson_pair_epi<float>(a, emode, false, gridp, st); }
     else if (dtype == QMG_C64) {
       if (a.nrhs == 1) { if (zero) k_wilson_pair<double, true, false><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, false><<<gridp, BLOCK, 0, st>>>(a); }
       else { if (zero) k_wilson_pair<double, true, true><<<gridp, BLOCK, 0, st>>>(a); else k_wilson_pair<double, false, true><<<gridp, BLOCK, 0, st>>>(a); }
@@ -645,8 +698,9 @@ static int wilson_direct_impl(int dtype, const qmg_stencil_desc* d, const void* 
     QMG_LAUNCH_CHECK();
     return epi_finish();
   }
+  epi_cap(grid);
   if (!epi_begin(grid)) return QMG_ERR_HIP;
-  if (a.epi.on) { if (dtype == QMG_C64) launch_wilson_epi<double>(a, shape, grid, st); else launch_wilson_epi<float>(a, shape, grid, st); }
+  if (a.epi.on) { if (dtype == QMG_C64) launch_wilson_epi<double>(a, shape, emode, grid, st); else launch_wilson_epi<float>(a, shape, emode, grid, st); }
   else if (dtype == QMG_C64) { if (a.nrhs == 1) launch_wilson_b<double, false>(a, shape, zero, grid, st); else launch_wilson_b<double, true>(a, shape, zero, grid, st); }
   else { if (a.nrhs == 1) launch_wilson_b<float, false>(a, shape, zero, grid, st); else launch_wilson_b<float, true>(a, shape, zero, grid, st); }
   QMG_LAUNCH_CHECK();

@@ -256,7 +256,15 @@ def test_rbjacobi_hops_from_the_links_reproduce_the_stored_stencil_solve(golden_
         assert p.returncode == 0 and "[QMG-ERROR]" not in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
         outs[flag] = [re.sub(r", t = [-\d.e+]+ s", "", l) for l in p.stdout.splitlines() if "TIMING" not in l]   # all but the wall-clock text
     if "f32" not in extra:
-        assert outs["1"] == outs["0"]
+        # the APPLIES are bit-identical; the smoothers' <p,r>, <p,p> are not any more: from the links they come out of kernel W's epilogue
+        # (per-wavefront partial sums), from the stored stencil out of a separate pass -- same numbers, different summation order.  So:
+        # the same lines, the same iteration counts, residuals equal to 1e-6.
+        assert len(outs["1"]) == len(outs["0"])
+        num = re.compile(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?")
+        for a, b in zip(outs["1"], outs["0"]):
+            assert num.sub("#", a) == num.sub("#", b), (a, b)
+            for u, v in zip(num.findall(a), num.findall(b)):
+                assert abs(float(u) - float(v)) <= 1e-6 * max(abs(float(u)), abs(float(v))), (a, b)
     else:
         rows = {f: re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", "\n".join(o)) for f, o in outs.items()}
         assert len(rows["1"]) == 2 and len(rows["0"]) == 2
