@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_bmr_update(void* __restrict__ x_, con
     ldc_pack<T, W>(rin, i, rv);
     if (!XSET) ldc_pack<T, W>(x, i, xv);
 #pragma unroll
-    for (int w = 0; w < W; w++) { if (XSET) xv[w] = cmul(alpha, rv[w]); else cmac(xv[w], alpha, rv[w]); }
+    for (int w = 0; w < W; w++) { if (XSET) xv[w] = cmake(0.0, 0.0); cmac(xv[w], alpha, rv[w]); }   // (XSET: the accumulate on an explicit zero, bit for bit)
     stc_pack<T, W>(x, i, xv);
     if (rout) {
       ldb<T, W>(p, i, pv, bi.nt);

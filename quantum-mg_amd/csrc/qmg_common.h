@@ -221,6 +221,7 @@ void release_stencil_workspace();
 extern int g_setup_fused; // qmg_setup.hip; "setup_fused"
 extern int g_wilson_pair;
 extern long g_blas_nt_bytes;   // qmg_blas.hip; "blas_nt_mb"   // qmg_wilson.hip; "wilson_pair"
+extern int g_xfer_mfma;   // qmg_transfer_mfma.hip; "xfer_mfma"
 extern int g_xfer_pack;   // qmg_transfer.hip; "xfer_pack"
 extern int g_xfer_tile;   // qmg_transfer.hip; set through qmg_set_tuning("xfer_tile", v)
 extern int g_site_block, g_site_gy, g_site_generic;   // qmg_site.hip; "site_block", "site_gy", "site_generic"

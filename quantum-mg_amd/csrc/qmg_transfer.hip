@@ -525,6 +525,12 @@ static int launch_prolong(const void* nullvecs, int nvec, const void* coarse, vo
   return QMG_SUCCESS;
 }
 
+// qmg_transfer_mfma.hip: the batched transfers as contractions on the matrix cores (SITE_DECLINED: shapes not served there)
+int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fine, void* coarse, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
+                        long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st);
+int prolong_batch_mfma(int f32, const void* nullvecs, int nvec, const void* coarse, void* fine, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
+                       long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st);
+
 int g_xfer_pack = 1;   // tuning knob "xfer_pack": complex<float> transfer kernels move two elements per lane (16-byte accesses)
 int g_xfer_tile = 1;   // tuning knob "xfer_tile": 1 = batched transfer as LDS-tiled kernels, 0 = system by system
 
@@ -551,6 +557,12 @@ static int prolong_batch_impl(const void* nullvecs, int nvec, const void* coarse
   }
   for (int s0 = 0; s0 < bi.n; s0 += 8) {
     const int left = bi.n - s0;
+    {
+      const PassIds pi = make_pass(bi, s0);
+      const int rc = prolong_batch_mfma(sizeof(T) == 4, nullvecs, nvec, coarse, fine, g.fhr, g.fLy, g.fnc, g.chr, g.cLy, g.cnc, g.bx, g.by, g.fhalf_vol, g.fsize, pi.id, pi.n,
+                                        (long)cstride, (long)fstride, st);
+      if (rc != SITE_DECLINED) { if (rc) return rc; continue; }
+    }
     const int KB = left > 4 ? 8 : left > 2 ? 4 : 2;
     const int SX = prolong_tile_sites(g, nvec, KB);
     const size_t smem = (size_t)SX * (nvec * KB + 1) * sizeof(cplx);
@@ -581,6 +593,12 @@ static int restrict_batch_impl(const void* nullvecs, int nvec, const void* fine,
   const int nel = g.bx * g.by * g.fnc;
   for (int s0 = 0; s0 < bi.n; s0 += 8) {
     const int left = bi.n - s0;
+    {
+      const PassIds pi = make_pass(bi, s0);
+      const int rc = restrict_batch_mfma(sizeof(T) == 4, nullvecs, nvec, fine, coarse, g.fhr, g.fLy, g.fnc, g.chr, g.cLy, g.cnc, g.bx, g.by, g.fhalf_vol, g.fsize, pi.id, pi.n,
+                                         (long)cstride, (long)fstride, st);
+      if (rc != SITE_DECLINED) { if (rc) return rc; continue; }
+    }
     const int KB = left > 4 ? 8 : left > 2 ? 4 : 2;
     if (nel <= 32 && nvec <= 24 && g_xfer_tile != 2) {   // one element per lane, every load of a site in flight at once
 #define QMG_RS(KBV, NVTV) k_brestrict_small<T, KBV, NVTV><<<gx, BLOCK, 0, st>>>(nullvecs, nvec, fine, coarse, g, make_pass(bi, s0), (long)cstride, (long)fstride)

@@ -53,7 +53,8 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
 
   bool ok_ = true;
   long total_iters = 0;
-  double solve_s = 0.0, single_s = 0.0, worst = 0.0;
+  double solve_s = 0.0, single_s = 0.0, worst = 0.0, alloc_in_solve_s = 0.0;
+  long allocs_in_solve = 0;
   int max_diff_iter = 0, nver = 0;
   cout << setprecision(12);
   for (int k0 = 0; k0 < nrhs; k0 += per_batch) {
@@ -81,12 +82,15 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
       for (int rep = 0; rep < repeats; rep++) {
         qmg::bzero(y, n, all);
         qmg_stream_sync(0);
+        const qmg::AllocStats a0 = qmg::alloc_stats();
         auto t0 = std::chrono::steady_clock::now();
         inv = bgcr_core<double>(y, b_prep, (int)(schur ? n / 2 : n), max_iter, tol, restart_freq, apply_stencil_typed_batch<double>, (void*)&op0,
                                 f32_kcycle ? mg_preconditioner_batch_mixed : mg_preconditioner_batch<double>, (void*)&bk, all, true, &verb, "VPGCR-restart");
         qmg_stream_sync(0);
         const double t_rep = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (repeats > 1) cout << "[QMG-MRHS]: repeat " << rep << " solve " << t_rep << " s\n";
+        const qmg::AllocStats a1 = qmg::alloc_stats();
+        alloc_in_solve_s = a1.seconds - a0.seconds; allocs_in_solve = (a1.mallocs - a0.mallocs) + (a1.frees - a0.frees);
+        if (repeats > 1) cout << "[QMG-MRHS]: repeat " << rep << " solve " << t_rep << " s (of which " << alloc_in_solve_s << " s in " << allocs_in_solve << " device allocator calls)\n";
         if (rep == repeats - 1) solve_s += t_rep;
       }
       if (schur) reconstruct_M_batch(mg->get_stencil(0), solve_type, x, y, b, all);
@@ -135,11 +139,11 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
         mg->check_in(x1, 0);
       }
     }
-    qmg::VecPool::release_all();   // the next batch may have a different size
+    // (the pool reuses its blocks by capacity: nothing is released between batches)
   }
   if (print_ops_stats) print_ops_stats(stats_arg);
   cout << "[QMG-TIMING]: setup " << setup_s << " s ; batched solve of " << nrhs << " systems " << solve_s << " s ; aggregate outer iterations/s " << total_iters / solve_s
-       << " ; systems/s " << nrhs / solve_s << "\n";
+       << " ; systems/s " << nrhs / solve_s << " ; device allocator inside the last solve " << alloc_in_solve_s << " s in " << allocs_in_solve << " calls\n";
   if (nver > 0) {
     cout << "[QMG-MRHS-VERIFY]: worst relative solution difference " << worst << " ; largest iteration-count difference " << max_diff_iter << " ; one-at-a-time solves "
          << single_s * nrhs / nver << " s" << (nver < nrhs ? " (extrapolated)" : "") << " vs batched " << solve_s << " s = " << (single_s * nrhs / nver) / solve_s << "x\n";

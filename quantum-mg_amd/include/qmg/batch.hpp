@@ -159,8 +159,8 @@ namespace qmg {
 // the coarsest GCR 2 restart + 4; 15 % head-room.  (4096^2 Wilson, restart 64: ~75 GB per system -- 3 per 288 GB GPU.)
 inline int batch_systems_that_fit(StatefulMultigridMG* mg, int outer_basis, int want) {
   size_t free_b = 0, total_b = 0;
-  VecPool::release_all();   // give cached scratch of other lengths back first
   if (qmg_mem_info(&free_b, &total_b) != QMG_SUCCESS) return 1;
+  free_b += VecPool::cached_bytes();   // cached scratch is reused by the next solve (by capacity), not returned to the driver and re-requested
   double per_system = 0.0;
   const int nl = mg->get_num_levels();
   for (int i = 0; i < nl; i++) {
@@ -805,6 +805,20 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
     }
     qmg::bcxpy(z3, lhs, fine_size_solve, mask);
   }
+}
+
+// Scratch of one K-cycle-preconditioned flexible GCR solve, allocated up front (qmg::VecPool::reserve): the outer solve's residual / work
+// vectors and 2 x outer_basis search directions of `outer_size` elements, and per level what one visit of mg_preconditioner_batch and the
+// level's inner GCR (a handful of iterations at its tolerance of 0.2) check out.  An estimate, not a contract: whatever a solve needs
+// beyond it is allocated on demand as before, and the drivers' timing lines say how long the allocator ran inside the solve.
+inline bool qmg_reserve_kcycle_scratch(StatefulMultigridMG* mg, size_t outer_size, int outer_basis, int nrhs = 1) {
+  bool good = qmg::VecPool::reserve(outer_size * (size_t)nrhs, 2 * outer_basis + 6);
+  const int nl = mg->get_num_levels();
+  for (int l = 0; l < nl && good; l++) {
+    const size_t n = (size_t)mg->get_lattice(l)->get_size_cv_l() * (size_t)nrhs;
+    good = qmg::VecPool::reserve(n, l == 0 ? 10 : 40);
+  }
+  return good;
 }
 
 // StatefulMultigridMG::mg_preconditioner for one system through this engine (declared in multigrid.hpp).  QMG_KCYCLE_ENGINE=single

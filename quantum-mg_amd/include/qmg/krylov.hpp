@@ -24,23 +24,65 @@
 
 namespace qmg {
 
-// Scratch vectors for one solve.  Returned to a per-length free list on scope exit instead of
-// hipFree (which synchronises the device): the smoothers run thousands of times per solve.
+// Scratch vectors for one solve.  Returned to a free list on scope exit instead of hipFree (which synchronises the device): the smoothers run
+// thousands of times per solve.  The free list is kept BY CAPACITY: a request for n elements takes the smallest cached block that holds
+// n and is not more than twice as large (so the complex<double> scratch of one solve serves the complex<float> batch of the next, and a
+// Schur system's half-length vectors fit a full-length block) -- a K-cycle solve that follows another one in the same process then runs
+// without a single hipMalloc in its timed region (GB-sized hipMalloc / hipFree calls cost milliseconds each and synchronise).
 struct VecPool {
   std::vector<complex<double>*> v;
   size_t n;
   // per host thread (a thread = one stream = one rank when ranks are emulated by threads: qmg_comm_emulate_*)
-  static std::map<size_t, std::vector<complex<double>*>>& cache() { static thread_local std::map<size_t, std::vector<complex<double>*>> c; return c; }
+  struct Shared {
+    std::map<size_t, std::vector<complex<double>*>> free_by_cap;   // capacity (elements) -> cached blocks
+    std::map<complex<double>*, size_t> cap;                         // every block this pool system has allocated and not yet freed
+    size_t cached_elems;
+    Shared() : cached_elems(0) {}
+  };
+  static Shared& shared() { static thread_local Shared s; return s; }
   explicit VecPool(size_t n_) : n(n_) {}
   complex<double>* get() {
-    std::vector<complex<double>*>& fl = cache()[n];
-    complex<double>* p;
-    if (!fl.empty()) { p = fl.back(); fl.pop_back(); } else { p = allocate_vector<complex<double>>(n); }
+    Shared& sh = shared();
+    complex<double>* p = 0;
+    for (auto it = sh.free_by_cap.lower_bound(n); it != sh.free_by_cap.end() && it->first <= 2 * n; ++it)
+      if (!it->second.empty()) { p = it->second.back(); it->second.pop_back(); sh.cached_elems -= it->first; break; }
+    if (!p) {
+      p = allocate_vector<complex<double>>(n);
+      if (p) sh.cap[p] = n;
+    }
     v.push_back(p);
     return p;
   }
-  ~VecPool() { std::vector<complex<double>*>& fl = cache()[n]; for (auto p : v) fl.push_back(p); }
-  static void release_all() { for (auto& kv : cache()) for (auto& p : kv.second) deallocate_vector(&p); cache().clear(); }
+  ~VecPool() {
+    Shared& sh = shared();
+    for (auto p : v) {
+      if (!p) continue;
+      const size_t c = sh.cap[p];
+      sh.free_by_cap[c].push_back(p);
+      sh.cached_elems += c;
+    }
+  }
+  static size_t cached_bytes() { return shared().cached_elems * sizeof(complex<double>); }
+  // put `count` fresh blocks of n elements on the free list: a solver's scratch allocated BEFORE its timed region (the device allocator's
+  // cost for GB-sized blocks is erratic on this platform: 134 calls took 3 ms in one run and 0.66 s in the next, drivers' `[QMG-TIMING]` lines)
+  static bool reserve(size_t n, int count) {
+    Shared& sh = shared();
+    for (int i = 0; i < count; i++) {
+      complex<double>* p = allocate_vector<complex<double>>(n);
+      if (!p) return false;
+      sh.cap[p] = n;
+      sh.free_by_cap[n].push_back(p);
+      sh.cached_elems += n;
+    }
+    return true;
+  }
+  static void release_all() {
+    Shared& sh = shared();
+    for (auto& kv : sh.free_by_cap)
+      for (auto& p : kv.second) { sh.cap.erase(p); deallocate_vector(&p); }
+    sh.free_by_cap.clear();
+    sh.cached_elems = 0;
+  }
 };
 
 inline void report(inversion_verbose_struct* verb, const char* name, int iter, double rel, bool summary_only = false) {

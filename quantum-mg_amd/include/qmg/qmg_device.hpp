@@ -12,6 +12,7 @@
 #include <complex>
 #include <cstddef>
 #include <cstdlib>
+#include <ctime>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -67,13 +68,26 @@ template <typename T> inline std::vector<T> to_host(const T* dev, size_t n) { st
 
 // ======================= quantum-linalg names, device semantics =======================
 
+namespace qmg {
+// how much wall time this thread has spent inside the device allocator (hipMalloc / hipFree synchronise and, for GB-sized buffers, are not
+// cheap): the drivers print it beside their solve times so that an allocation inside a timed region shows as what it is
+struct AllocStats { double seconds; long mallocs, frees; };
+inline AllocStats& alloc_stats() { static thread_local AllocStats s = {0.0, 0, 0}; return s; }
+inline double wall_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+}  // namespace qmg
 template <typename T> inline T* allocate_vector(size_t n) {
   void* p = nullptr;
-  if (!qmg::ok(qmg_malloc(&p, n * sizeof(T)), "allocate_vector")) return nullptr;
-  return static_cast<T*>(p);
+  const double t0 = qmg::wall_now();
+  const bool good = qmg::ok(qmg_malloc(&p, n * sizeof(T)), "allocate_vector");
+  qmg::alloc_stats().seconds += qmg::wall_now() - t0; qmg::alloc_stats().mallocs++;
+  return good ? static_cast<T*>(p) : nullptr;
 }
 template <typename T> inline void deallocate_vector(T** p) {
-  if (p && *p) { qmg_free(*p); *p = nullptr; }
+  if (p && *p) {
+    const double t0 = qmg::wall_now();
+    qmg_free(*p); *p = nullptr;
+    qmg::alloc_stats().seconds += qmg::wall_now() - t0; qmg::alloc_stats().frees++;
+  }
 }
 
 typedef complex<double> qmg_c;

@@ -316,8 +316,9 @@ def test_mr_step_with_device_scalars_is_the_host_scalar_step(nrhs, mask, dtype):
     dr, dp = mk(r0), mk(p0)
     d2 = qmg.batch_multidot_t(dt, [dr, dp], dp, n, nrhs, stride, mask)
     alpha = np.zeros(nrhs, dtype=np.complex128)
-    for k in act:
-        alpha[k] = omega * np.conj(d2[k, 0]) / d2[k, 1].real
+    for k in act:   # alpha = (omega <p,r>) / <p,p> component by component, as std::complex / double divides (numpy multiplies by a reciprocal)
+        pr, pp = np.conj(d2[k, 0]), d2[k, 1].real
+        alpha[k] = complex((omega * pr.real) / pp, (omega * pr.imag) / pp)
     wx, wr = mk(x0), mk(r0)
     qmg.batch_blas_t(dt, qmg.BOP_CAXPY, wx, n, nrhs, stride, mask, a=alpha, x=dr)
     qmg.batch_blas_t(dt, qmg.BOP_CAXPY, wr, n, nrhs, stride, mask, a=-alpha, x=dp)
