@@ -299,6 +299,7 @@ def kcycle_c5_schur_and_f32():
         res = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
         f = re.search(r"rhs 0 (converged|failed to converge) in (\d+) iterations ; alleged tolerance [\d.e+-]+ ; check tolerance ([\d.e+-]+)", p.stdout)
         ft = re.search(r"batched solve of 1 systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+)", p.stdout)
+        al = re.findall(r"device allocator inside the (?:last )?solve ([\d.e+-]+) s in (\d+) calls", p.stdout)
         out = {"workload": "adaptive Wilson K-cycle (n22 parameters, 1 adaptive pass), 4096x4096, 4 levels, coarse nc=8, red-black (Schur) on every level, 1 GPU",
                "metric": "outer VPGCR iterations per second", "returncode": p.returncode,
                "fp64": {"value": float(m.group(3)), "outer_iterations": int(it.group(2)), "converged": it.group(1) == "converged",
@@ -307,6 +308,9 @@ def kcycle_c5_schur_and_f32():
             out["fp32_kcycle"] = {"value": float(ft.group(2)), "outer_iterations": int(f.group(2)), "converged": f.group(1) == "converged",
                                   "true_residual_original_system": float(f.group(3)), "solve_s": float(ft.group(1)),
                                   "note": "K-cycle preconditioner entirely in complex<float> (vectors, matrices, null vectors); outer VPGCR, tolerance and residual check fp64"}
+            out["fp32_over_fp64"] = out["fp32_kcycle"]["value"] / out["fp64"]["value"]
+        if al:
+            out["device_allocator_inside_solves_s"] = [float(a[0]) for a in al]
         return out
     except Exception as e:
         return {"error": repr(e)}
@@ -560,7 +564,7 @@ def pmc_traffic(L):
     import hashlib
     src = os.path.join(ROOT, "quantum-mg_amd", "csrc", "qmg_stencil.hip")
     sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
         if L == 4096 and os.path.exists(path):
             pmc = json.load(open(path))
@@ -599,12 +603,14 @@ def kcycle_c3(extra_env=None):
         it = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", p.stdout)
         res = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
         ops = re.findall(r"Level (\d) .* Total (\d+)", p.stdout)
+        al = re.search(r"device allocator inside the solve ([\d.e+-]+) s in (\d+) calls", p.stdout)
         f32c = "complex<float>" in p.stdout
         return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, fp64, 1 GPU" + ("; Galerkin matrices of the preconditioner levels stored as complex<float> (the facade's default), arithmetic and vectors fp64" if f32c else ""),
                 "metric": "outer VPGCR iterations per second",
                 "value": float(m.group(3)), "outer_iterations": int(it.group(2)), "converged": it.group(1) == "converged",
                 "true_residual": float(res.group(1)), "solve_s": float(m.group(2)), "setup_s": float(m.group(1)),
-                "operator_applies_per_level": {l: int(t) for l, t in ops}, "returncode": p.returncode}
+                "operator_applies_per_level": {l: int(t) for l, t in ops}, "returncode": p.returncode,
+                "device_allocator_inside_solve_s": float(al.group(1)) if al else None}
     except Exception as e:   # the headline number must not be lost to a problem in the extra measurement
         return {"error": repr(e)}
 

@@ -434,8 +434,9 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *                   (kernel W2), 2 = W2 on two rows per lane group for one system on an even run of rows, else as 1 (2)
  *   "xfer_pack"     1: complex<float> single-system restrict / prolong move two elements per lane (16-byte accesses) (1)
  *   "xfer_tile"     1: batched restrict / prolong as LDS-tiled kernels; 0: the one-system kernels, system by system (1)
- *   "xfer_mfma"     1: batched restrict / prolong (2-16 systems) as contractions on the f64 matrix cores where the block shape allows
- *                   (even block width, <= 32 null vectors, a chunk of the tile within 60 KB of LDS); 0: the vector-FMA kernels (1)
+ *   "xfer_mfma"     batched restrict / prolong (2-16 systems) as contractions on the f64 matrix cores (even block width, <= 32 null vectors, a
+ *                   chunk of the tile within 60 KB of LDS): 1 = where that is the faster kernel (the complex<float> restrict), 2 = every served
+ *                   shape, 0 = never (1)
  *   "setup_fused"   1: block-local setup kernels (block orthonormalisation in LDS, Galerkin build as per-block products);
  *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)
  *   "malloc_poison" 1: qmg_malloc fills every allocation with 0xFF bytes (NaNs in every storage precision): a buffer read before

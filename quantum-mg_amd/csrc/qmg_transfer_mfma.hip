@@ -26,7 +26,11 @@
 
 namespace qmg {
 
-int g_xfer_mfma = 0;   // tuning knob "xfer_mfma": 1 = batched restrict / prolong on the matrix cores where the shapes allow; 0 (default) = the vector-FMA kernels
+// tuning knob "xfer_mfma": 1 (default) = the matrix cores where they are the faster kernel -- the complex<float> restrict (2048^2 -> 512^2 x 24, 8 systems:
+// 1.49 -> 1.10 ms; 512^2 -> 128^2: 1.10 -> 0.59 ms; 4096^2 -> 1024^2 x 8: 2.77 -> 2.21 ms; profiles/r03_xfer_mfma.txt), where the vector-FMA kernel is
+// bound by its cross-lane sums; the fp64 restrict and both prolongs stay with the vector-FMA kernels, which are at or above the MFMA form there;
+// 2 = every shape the MFMA kernels serve (measurements); 0 = never
+int g_xfer_mfma = 1;
 
 struct XferGeomM {      // (the geometry of qmg_transfer.hip, restated: the two files share no header beyond qmg_common.h)
   int fhr, fLy, fnc, chr, cLy, cnc, bx, by;
@@ -78,6 +82,18 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
     v4d P[MT], Q[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) { P[t] = (v4d)(0); Q[t] = (v4d)(0); }
+    // the coarse values this lane will add into (column lr = system, rows 16 t + 4 i + lq = d), requested NOW: read after the tile loop
+    // they would add one full memory latency to every workgroup
+    ct cin[MT][4];
+    const long ci0 = (wv < nsx) ? m_coarse_site_index(g, cx0 + wv, cy) : 0;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int d = 16 * t + 4 * i + lq;
+        cin[t][i] = zero;
+        if (wv < nsx && lr < 8 && lr < ns && d < nvec) cin[t][i] = reinterpret_cast<const ct*>(coarse)[(long)m_pick_id(ids, lr) * cstride + ci0 * g.cnc + d];
+      }
     for (int c = 0; c < L.nchunk; c++) {
       const int rr0 = c * L.CR;
       __syncthreads();   // the previous chunk's operand reads are done
@@ -94,11 +110,20 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
             const int rl = pr / rowlen, u = pr - rl * rowlen;
             const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
             const int lidx = rl * (L.SX * G) + u;
-            for (int d = my_dg; d < nvec; d += dgroups) nt[(size_t)d * L.Dstride + lidx] = nul[(long)d * g.fsize + gbase];
-            for (int q = my_dg; q < 8; q += dgroups) {
-              ct fv = zero;
-              if (q < ns) fv = fin[(long)m_pick_id(ids, q) * fstride + gbase];
-              ft[(size_t)q * L.Fstride + lidx] = fv;
+            // batches of 8 loads in flight per thread, then the 8 LDS stores (a load -> store loop is one memory latency per element)
+            for (int d0 = my_dg; d0 < nvec; d0 += 8 * dgroups) {
+              ct v[8];
+#pragma unroll
+              for (int k = 0; k < 8; k++) { const int d = d0 + k * dgroups; v[k] = zero; if (d < nvec) v[k] = nul[(long)d * g.fsize + gbase]; }
+#pragma unroll
+              for (int k = 0; k < 8; k++) { const int d = d0 + k * dgroups; if (d < nvec) nt[(size_t)d * L.Dstride + lidx] = v[k]; }
+            }
+            {
+              ct v[8];
+#pragma unroll
+              for (int k = 0; k < 8; k++) { const int q = my_dg + k * dgroups; v[k] = zero; if (q < ns) v[k] = fin[(long)m_pick_id(ids, q) * fstride + gbase]; }
+#pragma unroll
+              for (int k = 0; k < 8; k++) { const int q = my_dg + k * dgroups; if (q < 8) ft[(size_t)q * L.Fstride + lidx] = v[k]; }
             }
           }
       }
@@ -135,11 +160,9 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
           const int d = 16 * t + 4 * i + lq;
           if (lr < 8 && lr < ns && d < nvec) {
             const double re = P[t][i] + qx, im = px - Q[t][i];     // Cr = P[q] + Q[q+8], Ci = P[q+8] - Q[q]
-            ct* o = cor + (long)m_pick_id(ids, lr) * cstride + ci * g.cnc + d;
-            const ct v = *o;
             ct w;
-            w.x = (T)((double)v.x + re); w.y = (T)((double)v.y + im);
-            *o = w;
+            w.x = (T)((double)cin[t][i].x + re); w.y = (T)((double)cin[t][i].y + im);
+            cor[(long)m_pick_id(ids, lr) * cstride + ci * g.cnc + d] = w;
           }
         }
     }
@@ -194,7 +217,13 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_mfma(const void* __restrict_
           const int rl = pr / rowlen, u = pr - rl * rowlen;
           const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
           const int lidx = rl * (L.SX * G) + u;
-          for (int d = my_dg; d < nvec; d += dgroups) nt[(size_t)d * L.Dstride + lidx] = nul[(long)d * g.fsize + gbase];
+          for (int d0 = my_dg; d0 < nvec; d0 += 8 * dgroups) {   // 8 loads in flight per thread, then the 8 LDS stores
+            ct v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int d = d0 + k * dgroups; v[k] = zero; if (d < nvec) v[k] = nul[(long)d * g.fsize + gbase]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int d = d0 + k * dgroups; if (d < nvec) nt[(size_t)d * L.Dstride + lidx] = v[k]; }
+          }
         }
       __syncthreads();
       if (wv < nsx) {
@@ -229,13 +258,18 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_mfma(const void* __restrict_
           const int rl = pr / rowlen, u = pr - rl * rowlen;
           const long gbase = m_run_base(g, cy, rr0 + rl, cx0) + u;
           const int lidx = rl * (L.SX * G) + u;
-          for (int q = my_dg; q < ns; q += dgroups) {
-            ct* o = fin + (long)m_pick_id(ids, q) * fstride + gbase;
-            const ct a = ot[(size_t)q * L.Fstride + lidx];
-            const ct v = *o;
-            ct w;
-            w.x = (T)((double)v.x + (double)a.x); w.y = (T)((double)v.y + (double)a.y);
-            *o = w;
+          ct v[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { const int q = my_dg + k * dgroups; v[k] = zero; if (q < ns) v[k] = fin[(long)m_pick_id(ids, q) * fstride + gbase]; }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int q = my_dg + k * dgroups;
+            if (q < ns) {
+              const ct a = ot[(size_t)q * L.Fstride + lidx];
+              ct w;
+              w.x = (T)((double)v[k].x + (double)a.x); w.y = (T)((double)v[k].y + (double)a.y);
+              fin[(long)m_pick_id(ids, q) * fstride + gbase] = w;
+            }
           }
         }
     }
@@ -302,7 +336,7 @@ static int prolong_mfma_t(const void* nullvecs, int nvec, const void* coarse, vo
 
 int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fine, void* coarse, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
                         long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st) {
-  if (!g_xfer_mfma) return SITE_DECLINED;
+  if (!g_xfer_mfma || (g_xfer_mfma == 1 && !f32)) return SITE_DECLINED;
   XferGeomM g = {fhr, fLy, fnc, chr, cLy, cnc, bx, by, fhalf_vol, fsize};
   PassIdsM ids;
   ids.n = n;
@@ -312,7 +346,7 @@ int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fin
 }
 int prolong_batch_mfma(int f32, const void* nullvecs, int nvec, const void* coarse, void* fine, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
                        long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st) {
-  if (!g_xfer_mfma) return SITE_DECLINED;
+  if (g_xfer_mfma < 2) return SITE_DECLINED;
   XferGeomM g = {fhr, fLy, fnc, chr, cLy, cnc, bx, by, fhalf_vol, fsize};
   PassIdsM ids;
   ids.n = n;

@@ -1,7 +1,7 @@
 # One GPU call that produces every round file under profiles/ (run on the GPU box: gpurun -- 'bash tools/collect_round_profiles.sh r02').
 # rocprofv3 gets the program itself after `--` (python3 file / a binary), counters in their own passes.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $R
 O=gpurun_out
@@ -25,6 +25,12 @@ QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_n13 -- quant
 python tools/solve_phase_profile.py $O/prof_n13 > $O/${TAG}_n13_solve_phase.json
 rm -rf $O/prof_n13
 echo n13 done
+QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_n22 -- quantum-mg_amd/drivers/n22_wilson_kcycle_adaptive 4096 -0.07 6.0 3 1 tests/golden/l64t64b60_heatbath.dat 64 schur nrhs=1 f32 > $O/${TAG}_n22_c5_schur_f32.log 2>&1
+python tools/solve_phase_profile.py $O/prof_n22 > $O/${TAG}_n22_c5_schur_f32_solve_phase.json
+rm -rf $O/prof_n22
+echo n22 done
+python tools/xfer_bench.py > $O/${TAG}_xfer_mfma.txt 2>&1
+echo xfer done
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 echo bench done
 python -c "
