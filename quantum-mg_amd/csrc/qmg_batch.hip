@@ -13,6 +13,7 @@
 // reductions use the same block partition and the same fixed-order second stage, so a batched inner product is
 // bit-identical to the unbatched one.
 #include <string.h>
+#include <time.h>
 
 #include <initializer_list>
 
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(BLOCK) void k_bmultidot(const BatchPtrs xs, int j0,
 }
 
 // stage 2: block (q, s) sums the nparts partials of output q of system slot s in a fixed order
+// done / flag / seq (flag != nullptr): the LAST block to finish publishes `seq` in a host-visible word after the results (system-scope
+// fences on both sides of the block count), so the host can pick the results up by polling that word instead of waiting for the
+// stream's completion signal (wait_results below).
 __global__ __launch_bounds__(BLOCK) void k_breduce_final(const double* __restrict__ partials, int nparts, int width, const BatchIdx bi, int out_width,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, unsigned* done = nullptr, unsigned long long* flag = nullptr,
+                                                         unsigned long long seq = 0) {
   __shared__ double sm[BLOCK / WAVE];
   const int q = blockIdx.x, s = blockIdx.y;
   const double* p = partials + (long)s * nparts * width;
@@ -192,6 +197,14 @@ __global__ __launch_bounds__(BLOCK) void k_breduce_final(const double* __restric
 #pragma unroll
     for (int w = 1; w < BLOCK / WAVE; w++) r += sm[w];
     out[(long)bi.id[s] * out_width + q] = r;
+    if (flag) {
+      __threadfence_system();
+      if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
+        atomicExch(done, 0u);
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -260,6 +273,9 @@ struct BatchWorkspace {
   double* mr = nullptr;         // device-resident scalars of the MR smoother: [system][4] = Re<p,r>, Im<p,r>, <p,p>, - (qmg_batch_mr_*)
   double* epi_part = nullptr;   // partials of an apply's MR epilogue ([system slot][wavefront][4]), grown on demand
   size_t epi_cap = 0;
+  unsigned* done = nullptr;              // blocks of the current final stage that have stored their result (device)
+  unsigned long long* flag = nullptr;    // host-pinned, coherent: sequence number of the last final stage whose results are in `pinned`
+  unsigned long long seq = 0;
   int device = -1;
 };
 static thread_local BatchWorkspace g_bws;
@@ -269,7 +285,12 @@ static int get_bws(BatchWorkspace** out) {
   QMG_HIP_CHECK(hipGetDevice(&dev));
   if (g_bws.device != dev) {
     QMG_HIP_CHECK(hipMalloc((void**)&g_bws.partials, sizeof(double) * BATCH_MAX * BRED_BLOCKS * 2 * BDOT_MAX));
-    QMG_HIP_CHECK(hipHostMalloc((void**)&g_bws.pinned, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX, hipHostMallocDefault));
+    QMG_HIP_CHECK(hipHostMalloc((void**)&g_bws.pinned, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX, hipHostMallocCoherent));
+    QMG_HIP_CHECK(hipHostMalloc((void**)&g_bws.flag, 64, hipHostMallocCoherent));
+    *g_bws.flag = 0;
+    g_bws.seq = 0;
+    QMG_HIP_CHECK(hipMalloc((void**)&g_bws.done, sizeof(unsigned)));
+    QMG_HIP_CHECK(hipMemset(g_bws.done, 0, sizeof(unsigned)));
     QMG_HIP_CHECK(hipMalloc((void**)&g_bws.result, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
     QMG_HIP_CHECK(hipMemset(g_bws.result, 0, sizeof(double) * BATCH_MAX * 2 * BDOT_MAX));
     QMG_HIP_CHECK(hipMalloc((void**)&g_bws.mr, sizeof(double) * BATCH_MAX * 4));
@@ -286,7 +307,36 @@ void release_batch_workspace() {   // qmg_shutdown (qmg_runtime.hip)
   if (g_bws.pinned) hipHostFree(g_bws.pinned);
   if (g_bws.mr) hipFree(g_bws.mr);
   if (g_bws.epi_part) hipFree(g_bws.epi_part);
+  if (g_bws.done) hipFree(g_bws.done);
+  if (g_bws.flag) hipHostFree(g_bws.flag);
   g_bws = BatchWorkspace();
+}
+
+// How a reduction's results reach the host.  A solver iteration is a chain of short kernels with one or two host decisions in it, and
+// hipStreamSynchronize costs ~15 us of completion-signal handling per decision on top of the kernels' own latency (profiles/r03_n13_solve_phase.json:
+// 8244 gaps of 22.8 us after k_breduce_final = 16 % of the C3 solve).  With "reduce_spin" (default 1) the final stage's last block publishes a
+// sequence number in coherent host memory behind its results and the host polls that word; the stream is NOT synchronised (later launches
+// are ordered behind the kernel anyway).  A poll that sees nothing for 2 s falls back to the synchronise, which also surfaces a launch error.
+int g_reduce_spin = 1;
+static inline bool spin_results(const BatchWorkspace* ws) { return g_reduce_spin != 0 && ws->flag != nullptr; }
+static int wait_results(BatchWorkspace* ws, bool flagged, hipStream_t st) {
+  if (flagged) {
+    const unsigned long long want = ws->seq;
+    volatile unsigned long long* f = ws->flag;
+    for (long spins = 0;; spins++) {
+      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == want) return QMG_SUCCESS;
+      if ((spins & 0xfff) == 0xfff) {
+        static thread_local double t0 = 0;
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+        if (spins == 0xfff) t0 = now;
+        else if (now - t0 > 2.0) break;
+      }
+    }
+  }
+  QMG_HIP_CHECK(hipStreamSynchronize(st));
+  return QMG_SUCCESS;
 }
 
 double* mr_epilogue_begin(int nsys, long npart) {
@@ -439,14 +489,17 @@ int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n
   // slabs of one lattice: the per-system results are summed over the ranks before they reach the host (every rank has
   // the same active mask: the lock-step decisions are taken on these very sums)
   const bool dist = dist_reductions_on();
-  k_breduce_final<<<dim3(2, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2, bi, 2, dist ? ws->result : ws->pinned);
+  const bool flagged = !dist && spin_results(ws);
+  if (flagged) k_breduce_final<<<dim3(2, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2, bi, 2, ws->pinned, ws->done, ws->flag, ++ws->seq);
+  else k_breduce_final<<<dim3(2, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2, bi, 2, dist ? ws->result : ws->pinned);
   QMG_LAUNCH_CHECK();
   if (dist) {
     rc = dist_allreduce(ws->result, 2 * nrhs, false, st);
     if (rc) return rc;
     QMG_HIP_CHECK(hipMemcpyAsync(ws->pinned, ws->result, sizeof(double) * 2 * nrhs, hipMemcpyDeviceToHost, st));
   }
-  QMG_HIP_CHECK(hipStreamSynchronize(st));
+  rc = wait_results(ws, flagged, st);
+  if (rc) return rc;
   for (int s = 0; s < bi.n; s++) { out_host[2 * bi.id[s]] = ws->pinned[2 * bi.id[s]]; out_host[2 * bi.id[s] + 1] = ws->pinned[2 * bi.id[s] + 1]; }
   return QMG_SUCCESS;
 }
@@ -488,14 +541,18 @@ int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y
     QMG_LAUNCH_CHECK();
   }
   const bool dist = dist_reductions_on();
-  k_breduce_final<<<dim3(2 * nj, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2 * nj, bi, 2 * nj, dist ? ws->result : ws->pinned);
+  const bool flagged = !dist && spin_results(ws);
+  if (flagged)
+    k_breduce_final<<<dim3(2 * nj, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2 * nj, bi, 2 * nj, ws->pinned, ws->done, ws->flag, ++ws->seq);
+  else k_breduce_final<<<dim3(2 * nj, (unsigned)bi.n), BLOCK, 0, st>>>(ws->partials, (int)g, 2 * nj, bi, 2 * nj, dist ? ws->result : ws->pinned);
   QMG_LAUNCH_CHECK();
   if (dist) {
     rc = dist_allreduce(ws->result, 2 * nj * nrhs, false, st);
     if (rc) return rc;
     QMG_HIP_CHECK(hipMemcpyAsync(ws->pinned, ws->result, sizeof(double) * 2 * nj * nrhs, hipMemcpyDeviceToHost, st));
   }
-  QMG_HIP_CHECK(hipStreamSynchronize(st));
+  rc = wait_results(ws, flagged, st);
+  if (rc) return rc;
   for (int s = 0; s < bi.n; s++)
     memcpy(out_host + (size_t)bi.id[s] * 2 * nj, ws->pinned + (size_t)bi.id[s] * 2 * nj, sizeof(double) * 2 * nj);
   return QMG_SUCCESS;

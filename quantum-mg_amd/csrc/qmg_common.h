@@ -213,6 +213,7 @@ inline Epilogue no_epilogue() { Epilogue e; e.other = nullptr; e.dotv = nullptr;
 double* mr_epilogue_begin(int nsys, long npart);
 int mr_epilogue_finish(const unsigned char* ids, int n, long npart, hipStream_t st);
 
+extern int g_reduce_spin;     // qmg_batch.hip; "reduce_spin"
 extern int g_malloc_poison;   // qmg_runtime.hip; "malloc_poison"
 // qmg_shutdown: the calling thread's reduction / norm workspaces (qmg_blas.hip, qmg_batch.hip, qmg_stencil.hip)
 void release_blas_workspace();

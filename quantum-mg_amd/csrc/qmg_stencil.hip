@@ -1306,6 +1306,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "wilson_pair")) { g_wilson_pair = value; return QMG_SUCCESS; }
   if (!strcmp(key, "setup_fused")) { g_setup_fused = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_mfma")) { g_xfer_mfma = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "reduce_spin")) { g_reduce_spin = value; return QMG_SUCCESS; }
   if (!strcmp(key, "malloc_poison")) { g_malloc_poison = value ? 1 : 0; return QMG_SUCCESS; }
   return QMG_ERR_INVALID;
 }

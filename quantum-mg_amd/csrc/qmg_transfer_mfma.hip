@@ -82,18 +82,6 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
     v4d P[MT], Q[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) { P[t] = (v4d)(0); Q[t] = (v4d)(0); }
-    // the coarse values this lane will add into (column lr = system, rows 16 t + 4 i + lq = d), requested NOW: read after the tile loop
-    // they would add one full memory latency to every workgroup
-    ct cin[MT][4];
-    const long ci0 = (wv < nsx) ? m_coarse_site_index(g, cx0 + wv, cy) : 0;
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int d = 16 * t + 4 * i + lq;
-        cin[t][i] = zero;
-        if (wv < nsx && lr < 8 && lr < ns && d < nvec) cin[t][i] = reinterpret_cast<const ct*>(coarse)[(long)m_pick_id(ids, lr) * cstride + ci0 * g.cnc + d];
-      }
     for (int c = 0; c < L.nchunk; c++) {
       const int rr0 = c * L.CR;
       __syncthreads();   // the previous chunk's operand reads are done
@@ -160,9 +148,13 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_mfma(const void* __restrict
           const int d = 16 * t + 4 * i + lq;
           if (lr < 8 && lr < ns && d < nvec) {
             const double re = P[t][i] + qx, im = px - Q[t][i];     // Cr = P[q] + Q[q+8], Ci = P[q+8] - Q[q]
+            // (read here, not before the tile loop: held across it the eight values cost restrict<float, 2> a wavefront of occupancy -- 155 VGPRs --
+            // and 2048^2 -> 512^2 x 24 went from 1.10 back to 1.49 ms)
+            ct* o = cor + (long)m_pick_id(ids, lr) * cstride + ci * g.cnc + d;
+            const ct v = *o;
             ct w;
-            w.x = (T)((double)cin[t][i].x + re); w.y = (T)((double)cin[t][i].y + im);
-            cor[(long)m_pick_id(ids, lr) * cstride + ci * g.cnc + d] = w;
+            w.x = (T)((double)v.x + re); w.y = (T)((double)v.y + im);
+            *o = w;
           }
         }
     }
@@ -337,6 +329,8 @@ static int prolong_mfma_t(const void* nullvecs, int nvec, const void* coarse, vo
 int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fine, void* coarse, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
                         long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st) {
   if (!g_xfer_mfma || (g_xfer_mfma == 1 && !f32)) return SITE_DECLINED;
+  // half-filled MFMA columns on the thinnest contraction (4096^2 nc 2 -> 1024^2 x 8 with <= 4 systems: 1.89 ms against the vector kernel's 1.36)
+  if (g_xfer_mfma == 1 && n <= 4 && nvec <= 8 && fnc <= 2) return SITE_DECLINED;
   XferGeomM g = {fhr, fLy, fnc, chr, cLy, cnc, bx, by, fhalf_vol, fsize};
   PassIdsM ids;
   ids.n = n;

@@ -214,7 +214,7 @@ int main(int argc, char** argv) {
   }
   // ---- coarse shift after a variant swap (deliberate deviation from coarse.h:131, which leaves shift_backup at 0)
   {
-    const int nvec = 4;
+    const int nvec = 8;
     Lattice2D latc(L / 4, L / 4, nvec);
     Wilson2D wm(&lat2, complex<double>(0.13, 0.0), gauge);
     complex<double>** nv = new complex<double>*[nvec];
@@ -228,6 +228,16 @@ int main(int argc, char** argv) {
     zero_vector(a2, ncv); co.apply_M_dagger(a2, v);   // swaps the dagger stencil in and out again
     zero_vector(a2, ncv); co.apply_M(a2, v);
     check(co.get_shift() == complex<double>(0.13, 0.0) && diffnorm2sq(a1, a2, ncv) == 0.0, "coarse operator keeps its (non-zero) shift across a dagger swap", co.get_shift().real());
+    // the complex<float> copies of enable_f32_matrices mirror the ORIGINAL arrays: while the dagger stencil is swapped in they must not be applied
+    zero_vector(a1, ncv); co.apply_M_dagger(a1, v);
+    const bool f32on = co.enable_f32_matrices();
+    zero_vector(a2, ncv); co.apply_M_dagger(a2, v);
+    check(f32on && diffnorm2sq(a1, a2, ncv) == 0.0, "apply_M_dagger is untouched by fp32-stored ORIGINAL matrices", sqrt(diffnorm2sq(a1, a2, ncv) / norm2sq(a1, ncv)));
+    zero_vector(a1, ncv); co.apply_M(a1, v);
+    co.disable_f32_matrices();
+    zero_vector(a2, ncv); co.apply_M(a2, v);
+    const double d32 = sqrt(diffnorm2sq(a1, a2, ncv) / norm2sq(a2, ncv));
+    check(d32 > 0.0 && d32 < 1e-6, "apply_M with fp32-stored matrices is the fp64 apply to fp32 rounding", d32);
     for (complex<double>** p : {&v, &a1, &a2}) deallocate_vector(p);
     for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
     delete[] nv;

@@ -128,6 +128,9 @@ inline int N13::build(int argc, char** argv) {
   const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
   const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
   seed = 1337ull;
+  // QMG_SMOOTHER=cgne: the K-cycle's smoothers in their CGNE form (LevelSolveMG::pre_cgne / post_cgne, stateful_multigrid.h:847-857: MR on M M^dagger,
+  // then M^dagger) on every level; needs the dagger stencil of every smoothed level.  No reference test sets the flags; the default is plain MR.
+  const bool cgne = getenv("QMG_SMOOTHER") && std::string(getenv("QMG_SMOOTHER")) == "cgne";
   // null-vector relaxation: QMG_NULL_BATCH systems in lock step (default 8; 1 = one at a time in the reference's order, n13:340-366),
   // on complex<float> copies of the level's operator unless QMG_NULL_F32=0 (the relaxation stops at 5e-5)
   int null_batch = getenv("QMG_NULL_BATCH") ? atoi(getenv("QMG_NULL_BATCH")) : 8;
@@ -162,6 +165,7 @@ inline int N13::build(int argc, char** argv) {
   qmg_driver::phase("setup: fine operator", root);
   auto t_setup0 = std::chrono::steady_clock::now();
   wilson_op = new Wilson2D(lats[0], mass, gauge_field);
+  if (cgne) wilson_op->build_dagger_stencil();
   level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
   coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
   coarsest_solve_obj->coarsest_stencil_app = QMG_MATVEC_ORIGINAL;
@@ -235,7 +239,9 @@ inline int N13::build(int argc, char** argv) {
     level_solve_objs[i - 1]->pre_iters = n_pre_smooth;
     level_solve_objs[i - 1]->post_tol = post_smooth_tol;
     level_solve_objs[i - 1]->post_iters = n_post_smooth;
-    mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, true, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL, null_vectors);
+    level_solve_objs[i - 1]->pre_cgne = level_solve_objs[i - 1]->post_cgne = cgne;
+    mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, true, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL,
+                          cgne ? CoarseOperator2D::QMG_COARSE_BUILD_DAGGER : CoarseOperator2D::QMG_COARSE_BUILD_ORIGINAL, null_vectors);
     auto t3 = now();
     t_null += secs(t0, t1); t_ortho += secs(t1, t2); t_galerkin += secs(t2, t3);
     for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
@@ -243,6 +249,7 @@ inline int N13::build(int argc, char** argv) {
     if (root) cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built\n";
   }
   qmg_stream_sync(0);
+  if (root && cgne) cout << "[QMG-INFO]: CGNE smoothers (MR on M M^dagger, then M^dagger) on every level\n";
   if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
   if (root) cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin

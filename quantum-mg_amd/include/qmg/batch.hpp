@@ -212,10 +212,20 @@ template <typename T>
 inline void apply_M_overwrite_batch_t(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
   st->launch_set_batch<T>(QMG_P_ALL | QMG_P_ZERO, lhs.p, rhs.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, lhs.nrhs, lhs.stride, mask);
 }
+// lhs_k = M M^dagger rhs_k (apply_M_M_dagger, stencil_2d.h:1404-1416): the operator of the CGNE smoothers
+template <typename T>
+inline void apply_M_M_dagger_batch(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  qmg::BatchPoolT<T> pool(lhs.stride, lhs.nrhs);
+  qmg::BatchT<T> t = pool.get();
+  if (!t.p || !st->apply_M_dagger_overwrite_batch_t<T>(t.p, rhs.p, lhs.nrhs, lhs.stride, mask)) return;
+  apply_M_overwrite_batch_t<T>(st, lhs, t, mask);
+}
 template <typename T>
 inline void apply_stencil_typed_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask, void* extra_data) {
   BatchOp* op = (BatchOp*)extra_data;
   if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch<T>(op->st, lhs, rhs, mask);
+  else if (op->type == QMG_MATVEC_DAGGER) op->st->apply_M_dagger_overwrite_batch_t<T>(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
+  else if (op->type == QMG_MATVEC_M_MDAGGER) apply_M_M_dagger_batch<T>(op->st, lhs, rhs, mask);
   else apply_M_overwrite_batch_t<T>(op->st, lhs, rhs, mask);
 }
 // ---- the same applies with an EPILOGUE (Stencil2D::launch_set_epi), system by system, when ONE system is active: the BLAS-1 pass that
@@ -239,6 +249,17 @@ inline bool apply_op_fused(BatchOp* op, qmg::BatchT<T> out, qmg::BatchT<T> x, co
     // b - A x: out = 1 b + (-1) acc ; MR: out = acc, dots against x (= r)
     e.other = b ? (const void*)b->p : 0; e.other_scale = 1.0; e.acc_scale = b ? -1.0 : 1.0; e.dotv = mr_dots ? (const void*)x.p : 0;
     return st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, x.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e);
+  }
+  if (op->type == QMG_MATVEC_M_MDAGGER) {   // M (M^dagger x): the MR dots of the CGNE smoother (against x) ride on the second apply
+    if (b || !mr_dots) return false;
+    qmg::BatchPoolT<T> pool(out.stride, out.nrhs);
+    qmg::BatchT<T> t = pool.get();
+    if (!t.p || !st->apply_M_dagger_overwrite_batch_t<T>(t.p, x.p, out.nrhs, out.stride, mask)) return false;
+    e.other = 0; e.other_scale = 0.0; e.acc_scale = 1.0; e.dotv = (const void*)x.p;
+    if (st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, t.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e)) return true;
+    apply_M_overwrite_batch_t<T>(st, out, t, mask);
+    qmg::ok(qmg_batch_mr_dots_t(qmg::dtype_of<T>::value, x.p, out.p, (size_t)st->lat->get_size_cv_l(), out.nrhs, out.stride, mask, qmg::current_stream()), "qmg_batch_mr_dots");
+    return true;
   }
   if (op->type != QMG_MATVEC_RIGHT_SCHUR || !st->built_rbjacobi) return false;
   // Schur: A x = x_e - D'_eo D'_oe x_e.  First half plain (t_o = D'_oe x_e), second half with the epilogue on the even sites:
@@ -670,7 +691,10 @@ struct BatchKcycle {
     if (nl < 2) return false;
     for (int i = 0; i < nl - 1; i++) {
       StatefulMultigridMG::LevelSolveMG* ls = mg->get_level_solve(i);
-      if (!ls || !BatchOp::supported(ls->fine_stencil_app) || ls->pre_cgne || ls->post_cgne) return false;
+      if (!ls || !BatchOp::supported(ls->fine_stencil_app)) return false;
+      // CGNE smoothers (MR on M M^dagger, then M^dagger: stateful_multigrid.h:847-857, 1032-1042) act on the ORIGINAL operator and need its dagger
+      // stencil; on the Schur operator the reference ignores the flag
+      if ((ls->pre_cgne || ls->post_cgne) && ls->fine_stencil_app == QMG_MATVEC_ORIGINAL && !(mg->get_stencil(i) && mg->get_stencil(i)->built_dagger)) return false;
     }
     return BatchOp::supported(mg->get_coarsest_solve()->coarsest_stencil_app);
   }
@@ -726,27 +750,45 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   // scratch for this level (recycled through VecPool's per-length free lists)
   qmg::BatchPoolT<T> fpool(fine_size, nrhs), cpool(coarse_size, nrhs);
   qmg::BatchT<T> Atmp = fpool.get(), z1 = fpool.get(), r1 = fpool.get();
-  auto count = [&](QMGDslashType type, const std::vector<inversion_info>& inv, int lvl) {
-    for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) mg->add_tracker_count(type, inv[k].ops_count, lvl);
-  };
   int nact = 0;
   for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) nact++;
 
+  // One smoother application from x0 = 0: x ~ A^-1 b by `iters` steps of MR(0.85) -- or, `cgne` on the ORIGINAL operator, MR on M M^dagger y = b followed
+  // by x = M^dagger y (stateful_multigrid.h:847-857 / 1032-1042; on the Schur operator the reference ignores the flag).  Tolerances no MR step can
+  // reach take the fixed-count form with its scalars on the device, which can also hand back its recursive residual b - A x (r_out; in the CGNE
+  // form b - M M^dagger y is that same vector).  Returns whether r_out was filled.
+  auto smooth = [&](qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T>* r_out, int iters, double tol, bool cgne, QMGDslashType type) -> bool {
+    const bool ne = cgne && fine_type == QMG_MATVEC_ORIGINAL;
+    BatchOp ne_op(fine_stencil, QMG_MATVEC_M_MDAGGER);
+    BatchOp* op = ne ? &ne_op : &fine_op;
+    qmg::BatchT<T> y = ne ? fpool.get() : x;
+    if (!y.p) { std::cout << "[QMG-ERROR]: out of device memory for the CGNE smoother's iterate\n"; return false; }
+    bool have_r = false;
+    if (qmg::mr_tolerance_unreachable(tol) && qmg::kcycle_device_scalars()) {
+      const int nops = bmr_fixed_zero_guess<T>(y, b, r_out, (int)fine_size_solve, iters, 0.85, apply_stencil_typed_batch<T>, (void*)op, mask, op);
+      mg->add_tracker_count(type, (ne ? 2 : 1) * nops * nact, level);
+      have_r = r_out != 0;
+    } else {
+      qmg::bzero(y, fine_size, mask);
+      std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(y, b, (int)fine_size_solve, iters, tol, 0.85, apply_stencil_typed_batch<T>, (void*)op, mask);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) mg->add_tracker_count(type, (ne ? 2 : 1) * inv[k].ops_count, level);
+    }
+    if (ne) {
+      BatchOp dag(fine_stencil, QMG_MATVEC_DAGGER);
+      apply_stencil_typed_batch<T>(x, y, mask, (void*)&dag);
+      mg->add_tracker_count(type, nact, level);
+    }
+    return have_r;
+  };
+
   // ---- 1. pre-smooth: A z1 ~ rhs, r1 = rhs - A z1
-  const bool fixed_pre = level_solve->pre_iters > 0 && qmg::mr_tolerance_unreachable(level_solve->pre_tol) && qmg::kcycle_device_scalars();
-  if (fixed_pre) {
-    // fixed-count MR, scalars on the device; its recursive residual is r1 (the reference recomputes rhs - A z1 with one more
-    // apply, stateful_multigrid.h:863-866: the same vector up to rounding), so the smoother costs pre_iters applies, not pre_iters + 1
-    const int nops = bmr_fixed_zero_guess<T>(z1, rhs, &r1, (int)fine_size_solve, level_solve->pre_iters, 0.85, apply_stencil_typed_batch<T>, (void*)&fine_op, mask, &fine_op);
-    mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nops * nact, level);
-  } else if (level_solve->pre_iters > 0) {
-    qmg::bzero(z1, fine_size, mask);
-    std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z1, rhs, (int)fine_size_solve, level_solve->pre_iters, level_solve->pre_tol, 0.85,
-                                                                         apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
-    count(QMG_DSLASH_TYPE_PRESMOOTH, inv, level);
-    apply_stencil_typed_batch<T>(Atmp, z1, mask, (void*)&fine_op);
-    mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
-    qmg::bxmyz(rhs, Atmp, r1, fine_size_solve, mask);
+  if (level_solve->pre_iters > 0) {
+    // the fixed-count form's recursive residual is r1 (the reference recomputes rhs - A z1 with one more apply, stateful_multigrid.h:863-866:
+    // the same vector up to rounding), so that smoother costs pre_iters applies, not pre_iters + 1
+    if (!smooth(z1, rhs, &r1, level_solve->pre_iters, level_solve->pre_tol, level_solve->pre_cgne, QMG_DSLASH_TYPE_PRESMOOTH)) {
+      apply_op_residual<T>(&fine_op, r1, z1, rhs, Atmp, fine_size_solve, mask);
+      mg->add_tracker_count(QMG_DSLASH_TYPE_PRESMOOTH, nact, level);
+    }
   } else {
     qmg::bzero(z1, fine_size, mask);
     qmg::bcopy(r1, rhs, fine_size_solve, mask);
@@ -794,15 +836,7 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   if (level_solve->post_iters > 0) {
     qmg::BatchT<T> r2 = z2, z3 = z1;   // both free again
     apply_op_residual<T>(&fine_op, r2, lhs, rhs, Atmp, fine_size_solve, mask);   // r2 = rhs - A lhs
-    if (qmg::mr_tolerance_unreachable(level_solve->post_tol) && qmg::kcycle_device_scalars()) {
-      const int nops = bmr_fixed_zero_guess<T>(z3, r2, (qmg::BatchT<T>*)0, (int)fine_size_solve, level_solve->post_iters, 0.85, apply_stencil_typed_batch<T>, (void*)&fine_op, mask, &fine_op);
-      mg->add_tracker_count(QMG_DSLASH_TYPE_POSTSMOOTH, nops * nact, level);
-    } else {
-      qmg::bzero(z3, fine_size, mask);
-      std::vector<inversion_info> inv = bminv_vector_minres_zero_guess<T>(z3, r2, (int)fine_size_solve, level_solve->post_iters, level_solve->post_tol, 0.85,
-                                                                           apply_stencil_typed_batch<T>, (void*)&fine_op, mask);
-      count(QMG_DSLASH_TYPE_POSTSMOOTH, inv, level);
-    }
+    smooth(z3, r2, (qmg::BatchT<T>*)0, level_solve->post_iters, level_solve->post_tol, level_solve->post_cgne, QMG_DSLASH_TYPE_POSTSMOOTH);
     qmg::bcxpy(z3, lhs, fine_size_solve, mask);
   }
 }

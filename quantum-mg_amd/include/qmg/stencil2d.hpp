@@ -83,7 +83,7 @@ struct Stencil2D {
       if (rc == QMG_SUCCESS) return;
       if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
     }
-    if (f32_matrices && cl == clover && ho == hopping) {   // opt-in fp32 storage of the ORIGINAL stencil (enable_f32_matrices)
+    if (f32_in_use() && cl == clover && ho == hopping) {   // opt-in fp32 storage of the ORIGINAL stencil (enable_f32_matrices)
       d.clover = clover32; d.hopping = hopping32;
       qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat32");
       return;
@@ -102,6 +102,8 @@ struct Stencil2D {
   complex<double> shift, eo_shift, dof_shift;
   // opt-in: complex<float> copies of clover / hopping that the ORIGINAL-operator applies stream instead of the fp64 arrays
   bool f32_matrices;
+  // the fp32 copies mirror the ORIGINAL arrays: while a variant (dagger, rbjacobi, rbj-dagger) is swapped into clover / hopping they do not apply
+  bool f32_in_use() const { return f32_matrices && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger; }
   void* clover32;
   void* hopping32;
 
@@ -110,11 +112,18 @@ struct Stencil2D {
   // The fp64 arrays stay the master copy; enable_f32_shadow() (re)creates the copies from their current contents.
   struct F32Shadow {
     void* clover; void* hopping; void* rbj_hopping; void* rbj_cinv; bool on;
+    void* dagger_clover; void* dagger_hopping;   // when the dagger stencil is built (CGNE smoothers of the fp32 K-cycle)
     // optional (nc = 2): complex<half> copies of the matrices the smoother / residual applies of the fp32 K-cycle stream
     // (qmg_stencil_apply_h16: 112 B/site); cinv stays fp32 (it is applied once per cycle)
     void* clover16; void* hopping16; void* rbj_hopping16; bool half_on;
   } f32;
-  enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2 };
+  // QMG_ARR_DAGGER: the dagger stencil (build_dagger_stencil) by name, without perform_swap_dagger -- the batch engine's CGNE smoothers; the caller passes
+  // the conjugated shifts
+  enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2, QMG_ARR_DAGGER = 3 };
+  const void* clover_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? clover : set == QMG_ARR_RBJ_CINV ? rbjacobi_cinv : set == QMG_ARR_DAGGER ? dagger_clover : 0; }
+  const void* hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? hopping : set == QMG_ARR_RBJ_HOPPING ? rbjacobi_hopping_in_use() : set == QMG_ARR_DAGGER ? dagger_hopping : 0; }
+  const void* f32_clover_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? f32.clover : set == QMG_ARR_RBJ_CINV ? f32.rbj_cinv : set == QMG_ARR_DAGGER ? f32.dagger_clover : 0; }
+  const void* f32_hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? f32.hopping : set == QMG_ARR_RBJ_HOPPING ? f32.rbj_hopping : set == QMG_ARR_DAGGER ? f32.dagger_hopping : 0; }
 
   // Operators whose stencil is a fixed spin pattern times the gauge links (Wilson2D) can be applied straight from the links
   // (qmg_wilson_apply_direct, csrc/qmg_wilson.hip: 96 B/site instead of 384, bit-identical to the stored stencil through the
@@ -242,6 +251,7 @@ struct Stencil2D {
     eo_cvector = 0;
     f32_matrices = false; clover32 = hopping32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
+    f32.dagger_clover = f32.dagger_hopping = 0;
     direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false; direct.rbj_scale = 0.0;
     slab_halo_lo = slab_halo_hi = 0;
     slab_comm_stream = slab_ev_rhs = slab_ev_halo = 0;
@@ -280,6 +290,7 @@ struct Stencil2D {
     if (swap_dagger || swap_rbjacobi || swap_rbj_dagger) { std::cout << "[QMG-ERROR]: enable_f32_shadow called while a stencil variant is swapped in.\n"; return false; }
     bool good = dup(&f32.clover, clover, lat->get_size_cm_l()) && dup(&f32.hopping, hopping, lat->get_size_hopping_l());
     if (good && built_rbjacobi) good = dup(&f32.rbj_hopping, rbjacobi_hopping, lat->get_size_hopping_l()) && dup(&f32.rbj_cinv, rbjacobi_cinv, lat->get_size_cm_l());
+    if (good && built_dagger) good = dup(&f32.dagger_clover, dagger_clover, lat->get_size_cm_l()) && dup(&f32.dagger_hopping, dagger_hopping, lat->get_size_hopping_l());
     if (good && half_matrices) {
       auto dup16 = [&](void** dst, const complex<double>* src, long n) -> bool {
         if (src == 0) return true;
@@ -300,7 +311,7 @@ struct Stencil2D {
     return true;
   }
   void disable_f32_shadow() {
-    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv, &f32.clover16, &f32.hopping16, &f32.rbj_hopping16};
+    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv, &f32.clover16, &f32.hopping16, &f32.rbj_hopping16, &f32.dagger_clover, &f32.dagger_hopping};
     for (auto p : all) if (*p) { qmg_free(*p); *p = 0; }
     f32.on = false; f32.half_on = false;
   }
@@ -493,18 +504,18 @@ struct Stencil2D {
         if (rc == QMG_SUCCESS) return;
         if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_hops_direct"); return; }
       }
-      if (f && f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices (nc = 2), fp32 vectors
+      if (f && f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER) {   // 16-bit stored matrices (nc = 2), fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
         qmg::ok(qmg_stencil_apply_slab(QMG_C32 | QMG_SLAB_H16, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
         return;
       }
       if (f) {
-        d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
-        d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+        d.clover = f32_clover_of(set);
+        d.hopping = f32_hopping_of(set);
       } else {
-        d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
-        d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
+        d.clover = clover_of(set);
+        d.hopping = hopping_of(set);
       }
       qmg::ok(qmg_stencil_apply_slab(dt, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
       return;
@@ -523,20 +534,20 @@ struct Stencil2D {
     }
     if (sizeof(T) == sizeof(float)) {
       if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
-      if (f32.half_on && set != QMG_ARR_RBJ_CINV) {   // 16-bit stored matrices, fp32 vectors
+      if (f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER) {   // 16-bit stored matrices, fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
         qmg::ok(qmg_stencil_apply_h16(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_h16");
         return;
       }
-      d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
-      d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+      d.clover = f32_clover_of(set);
+      d.hopping = f32_hopping_of(set);
       qmg::ok(qmg_stencil_apply_t(QMG_C32, &d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_t");
       return;
     }
-    d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
-    d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
-    if (set == QMG_ARR_ORIGINAL && f32_matrices) {   // opt-in fp32 STORAGE of the coarse matrices, fp64 vectors (enable_f32_matrices)
+    d.clover = clover_of(set);
+    d.hopping = hopping_of(set);
+    if (set == QMG_ARR_ORIGINAL && f32_in_use()) {   // opt-in fp32 STORAGE of the coarse matrices, fp64 vectors (enable_f32_matrices)
       d.clover = clover32; d.hopping = hopping32;
       qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
       return;
@@ -576,14 +587,14 @@ struct Stencil2D {
     }
     int mat32 = 0;
     if (f) {
-      if (!f32.on || (f32.half_on && set != QMG_ARR_RBJ_CINV)) return false;
-      d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover : (set == QMG_ARR_RBJ_CINV) ? f32.rbj_cinv : 0;
-      d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping : (set == QMG_ARR_RBJ_HOPPING) ? f32.rbj_hopping : 0;
+      if (!f32.on || (f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER)) return false;
+      d.clover = f32_clover_of(set);
+      d.hopping = f32_hopping_of(set);
       mat32 = 1;
     } else {
-      d.clover = (set == QMG_ARR_ORIGINAL) ? clover : (set == QMG_ARR_RBJ_CINV) ? rbjacobi_cinv : 0;
-      d.hopping = (set == QMG_ARR_ORIGINAL) ? hopping : (set == QMG_ARR_RBJ_HOPPING) ? rbjacobi_hopping_in_use() : 0;
-      if (set == QMG_ARR_ORIGINAL && f32_matrices) { d.clover = clover32; d.hopping = hopping32; mat32 = 1; }
+      d.clover = clover_of(set);
+      d.hopping = hopping_of(set);
+      if (set == QMG_ARR_ORIGINAL && f32_in_use()) { d.clover = clover32; d.hopping = hopping32; mat32 = 1; }
     }
     return served(qmg_stencil_apply_epi_t(dt, mat32, &d, lhs, rhs, pieces, stride, system, &epi, qmg::current_stream()), "qmg_stencil_apply_epi_t") != 0;
   }
@@ -592,6 +603,18 @@ struct Stencil2D {
   // on the Galerkin coarse operators this is the f64-MFMA contraction of qmg_stencil.hip kernel C.
   void apply_M_overwrite_batch(complex<double>* lhs, complex<double>* rhs, int nrhs, size_t stride, unsigned mask) {
     launch_set_batch<double>(QMG_P_ALL | QMG_P_ZERO, lhs, rhs, QMG_ARR_ORIGINAL, shift, eo_shift, dof_shift, nrhs, stride, mask);
+  }
+  // lhs_k = M^dagger rhs_k for the active systems: the dagger stencil by name with the conjugated shifts (what perform_swap_dagger + apply_M do for
+  // one vector, :1142-1178).  false: the dagger stencil (or, for complex<float> vectors, its shadow) is not there; nothing was launched.
+  template <typename T>
+  bool apply_M_dagger_overwrite_batch_t(complex<T>* lhs, complex<T>* rhs, int nrhs, size_t stride, unsigned mask) {
+    if (!built_dagger || swap_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_dagger (batch), but the dagger stencil has not been allocated.\n"; return false; }
+    if (sizeof(T) == sizeof(float) && (!f32.on || (dagger_hopping != 0 && f32.dagger_hopping == 0))) {
+      std::cout << "[QMG-ERROR]: fp32 dagger apply without an fp32 shadow of the dagger stencil (build_dagger_stencil before enable_f32_shadow).\n";
+      return false;
+    }
+    launch_set_batch<T>(QMG_P_ALL | QMG_P_ZERO, lhs, rhs, QMG_ARR_DAGGER, std::conj(shift), std::conj(eo_shift), std::conj(dof_shift), nrhs, stride, mask);
+    return true;
   }
 
   complex<double> get_shift() { return shift; }

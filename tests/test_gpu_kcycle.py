@@ -208,6 +208,52 @@ def test_kcycle_with_f32_stored_coarse_operators(golden_dir):
     assert all(abs(a - b) <= 2 for a, b in zip(its["f64"], its["f32"])), its
 
 
+def test_cgne_smoothers_in_both_engines(golden_dir):
+    """LevelSolveMG::pre_cgne / post_cgne (stateful_multigrid.h:847-857, 1032-1042: MR on M M^dagger, then M^dagger; no reference test sets the flags, the
+    driver takes QMG_SMOOTHER=cgne).  The lock-step batch engine (dagger stencil by name, the MR dots riding on the second apply, fixed-count
+    device-scalar form) against the reference-shaped single-vector code of multigrid.hpp (perform_swap_dagger, minv_vector_minres on
+    apply_M_M_dagger): same outer iteration count, the same solution, true residual <= 1e-10; the trackers count what each engine performs
+    (per level visit 2 (2 x 2 + 1) smoother applies, plus the two residual applies the single-vector engine spends and the batch engine saves
+    one of).  Then three systems in lock step, fp64 and with the K-cycle in complex<float> (the dagger stencil's fp32 shadow)."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    res = {}
+    for tag, extra in (("batch", {}), ("single", {"QMG_KCYCLE_ENGINE": "single"}), ("mr", {"QMG_SMOOTHER": "mr"})):
+        with tempfile.TemporaryDirectory() as d:
+            env = dict(os.environ, QMG_QUIET="1", QMG_SMOOTHER="cgne", QMG_DUMP_DIR=d)
+            env.update(extra)
+            out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle"), "128", "-0.07", "6.0", "2", "8", gauge_file, "64"], cwd=DRIVERS, env=env,
+                                 capture_output=True, text=True, timeout=150)
+            assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+            assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+            assert ("CGNE smoothers" in out.stdout) == (tag != "mr")
+            it = int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1))
+            chk = float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
+            m = re.search(r"Level 0 NullVec 0 PreSmooth (\d+) Krylov 0 PostSmooth (\d+)", out.stdout)
+            x = np.fromfile(os.path.join(d, "x.bin"), dtype=np.complex128)
+            res[tag] = (it, chk, int(m.group(1)), int(m.group(2)), x)
+    for tag in res:
+        assert res[tag][1] <= 1.05e-10, (tag, res[tag][:4])
+    assert res["batch"][0] == res["single"][0], (res["batch"][:4], res["single"][:4])
+    rel = np.linalg.norm(res["batch"][4] - res["single"][4]) / np.linalg.norm(res["single"][4])
+    assert rel < 1e-8, rel
+    it = res["batch"][0]
+    # level-0 visits = outer iterations; smoother applies per visit: MR on M M^dagger costs 2 per step, + the closing M^dagger
+    assert res["batch"][2] == it * 5 and res["batch"][3] == it * 5, res["batch"][:4]
+    assert res["single"][2] == it * 6 and res["single"][3] == it * 5, res["single"][:4]
+    assert res["mr"][2] == res["mr"][0] * 2                                                                # (plain MR: 2 applies per visit)
+    for extra in ([], ["f32"]):
+        out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle_mrhs"), "128", "-0.07", "6.0", "2", "8", gauge_file, "64", "3", "verify"] + extra, cwd=DRIVERS,
+                             env=dict(os.environ, QMG_QUIET="1", QMG_SMOOTHER="cgne"), capture_output=True, text=True, timeout=200)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout and "CGNE smoothers" in out.stdout
+        rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+        assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-2000:]
+        ver = re.findall(r"\[QMG-MRHS-VERIFY\]: rhs (\d+) single-path iterations (\d+) \(batched (\d+)\) ; relative solution difference ([-\d.e+]+)", out.stdout)
+        assert len(ver) == 3
+        for _, single_it, batch_it, diff in ver:
+            assert abs(int(single_it) - int(batch_it)) <= (2 if extra else 1) and float(diff) < 1e-7
+
+
 def test_batched_schur_kcycle_reproduces_the_single_solves(golden_dir):
     """n19 configuration (even-odd Schur complement of the right-block-Jacobi operator on every level, four levels
     128 -> 32 -> 8 -> 2) for a lock-step batch: prepare / Schur solve / reconstruct per system, inner tolerances per

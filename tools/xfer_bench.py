@@ -32,10 +32,14 @@ for (fL, fnc, cL, cnc) in ((2048, 2, 512, 24), (512, 24, 128, 24), (4096, 2, 102
         nv = gauss(cnc * fsize, 5, dtype)
         for k in (4, 8):
             fb, cb = gauss(k * fsize, 31, dtype), gauss(k * csize, 32, dtype)
-            for mfma in (2, 0):
+            for mfma in (1, 2, 0):
                 qmg.set_tuning("xfer_mfma", mfma)
                 for op, fn in (("prolong", lambda: qmg.prolong_batch_t(dtype, nv, cnc, cb, fb, fd, cd, k, csize, fsize, (1 << k) - 1)),
                                ("restrict", lambda: qmg.restrict_batch_t(dtype, nv, cnc, fb, cb, fd, cd, k, fsize, csize, (1 << k) - 1))):
+                    # fresh operands for every measurement: the calls ACCUMULATE (fine += P coarse, coarse += P^dag fine), and a dozen rounds of that
+                    # overflow complex<float>
+                    fb.free(); cb.free()
+                    fb, cb = gauss(k * fsize, 31, dtype), gauss(k * csize, 32, dtype)
                     for _ in range(2):
                         fn()
                     qmg.sync()
