@@ -73,6 +73,16 @@ struct StencilArgs {
 #endif
 
 __device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)(a.use_idx ? (int)a.ridx[k] : k) * a.vec_stride; }
+// the same index for a PER-LANE k without touching memory: a.ridx[k] with a divergent k is a vector load from the kernel-argument segment,
+// and an address that waits for it puts a second memory latency in front of every vector load it feeds (kernel C: in front of every piece).
+// The sixteen bytes are four scalar registers; the lane picks its byte with selects and a shift.
+__device__ __forceinline__ int system_index(const StencilArgs& a, int k) {
+  if (!a.use_idx) return k;
+  unsigned w[4];
+  __builtin_memcpy(w, a.ridx, 16);
+  const unsigned ww = (k & 8) ? ((k & 4) ? w[3] : w[2]) : ((k & 4) ? w[1] : w[0]);
+  return (int)((ww >> (8 * (k & 3))) & 0xffu);
+}
 
 // vector element i of a complex<double> (V32 = false) or complex<float> (V32 = true) array, in fp64 registers
 template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i) { return V32 ? ldc<float>(base, i) : ldc<double>(base, i); }
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
   if (j >= a.hr) return;                      // whole wavefront leaves; the kernel has no block barriers
   const int kcol = (MODE == 1) ? (lr & 7) : lr;   // right-hand side this lane's MFMA column belongs to
   const bool kval = kcol < nk;                 // ... and whether it exists
-  const long koff = rhs_offset(a, kcol & 15);
+  const long koff = (long)system_index(a, kcol & 15) * a.vec_stride;
 
   for (int row = blockIdx.y; row < a.nrows; row += gridDim.y) {
     const int p = (a.par_count == 2) ? (row & 1) : a.par_first;
@@ -974,7 +984,21 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
     // staging registers for the matrix stream (a second set, two pieces of prefetch, was measured SLOWER: 8 rhs 2.88 -> 3.10
     // ms; the registers cost a resident wavefront and the stream was not the limit -- profiles/r02_mfma_kernelC_variants.txt)
     constexpr int NGS = M32 ? NGP : NG;
-    cplx G[1][NGS];   // M32: raw bits of two complex<float> per entry
+    // How many pieces of the matrix stream a wavefront keeps in flight (register sets): ONE.  Deeper prefetch was measured for every shape
+    // (-DQMG_KC_PFD_A/B/C = sets for <= 1 / <= 3 / <= 5 staged elements per lane; tools/kernelc_bench.py, gpurun_out/r03_kernelc_*.txt): two
+    // sets cost fp64 nc = 24 a resident wavefront (round 2: 2.88 -> 3.10 ms); for the half-size fp32-stored stream they fit (124 -> 147 VGPRs)
+    // and changed nothing (nc = 24, 8 systems: 1.43 -> 1.54 ms), and five sets at nc = 8 were slower (1.64 -> 1.83 ms): the wavefronts are
+    // parked 60 % of their cycles (SQ_WAIT_ANY) with the matrix pipe 37 % busy, but more loads in flight per wavefront do not shorten that.
+    // What did: the right-hand sides' system indices without a memory access (system_index) -- a.ridx[k] with a per-lane k is a vector load from
+    // the kernel arguments whose result the vector loads' addresses waited for, one more memory latency in front of every piece (fp64 nc = 24,
+    // 16 systems: 3.47 -> 2.90-3.00 ms; nc = 16 fp32-stored matrices, 8 systems: 0.905 -> 0.74 ms; nc = 12 fp64: 0.83 -> 0.75 ms).
+#ifndef QMG_KC_PFD_A
+#define QMG_KC_PFD_A 1
+#define QMG_KC_PFD_B 1
+#define QMG_KC_PFD_C 1
+#endif
+    constexpr int PFD = (NGS <= 1) ? QMG_KC_PFD_A : (NGS <= 3) ? QMG_KC_PFD_B : (NGS <= 5) ? QMG_KC_PFD_C : 1;
+    cplx G[PFD][NGS];   // M32: raw bits of two complex<float> per entry
     // Right-hand sides.  VL = false (round 1): each lane loads its B-operand entries X_k[4q + lq] straight from global memory --
     // 16 right-hand sides x 64-byte pieces per instruction, 16 cache lines touched per load, 6 loads per piece; going from 4
     // to 8 right-hand sides cost 0.48 ms of a 2.9 ms apply.  VL = true: the piece's nk x NC block is loaded COALESCED
@@ -984,7 +1008,13 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
     constexpr int XS = NC + 1;                                   // padded row of the vector slice
     constexpr int XROWS = (MODE == 1) ? 8 : 16;                  // right-hand sides a pass can hold (MODE 1: at most 8)
     constexpr int NXG = (XROWS * NC + WAVE - 1) / WAVE;          // staged vector elements per lane per piece
-    cplx XG[VL ? NXG : 1];
+    constexpr int XPF = (VL && NXG <= 2) ? PFD : 1;               // ... and of the right-hand sides (small blocks only: nc = 8, 12)
+    cplx XG[XPF][VL ? NXG : 1];
+    int ksys[VL ? NXG : 1];   // the system each of this lane's staged vector elements belongs to (row-invariant, no memory access: system_index)
+    if constexpr (VL) {
+#pragma unroll
+      for (int g = 0; g < NXG; g++) { const int k = (g * WAVE + lane) / NC; ksys[g] = system_index(a, k < 16 ? k : 0); }
+    }
     cplx* xlds = reinterpret_cast<cplx*>(smem_raw + (M32 ? sizeof(float2) : sizeof(cplx)) * (size_t)(BLOCK / WAVE) * NC * RS) + (size_t)wave * XROWS * XS;
     // MODE 1 needs only the half of X its column carries (re for columns 0-7, im for 8-15): one double per k-step
     typename std::conditional<MODE == 1, double, cplx>::type B[2][VL ? 1 : KS];
@@ -1012,22 +1042,22 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         }
       }
     };
-    auto load_vectors = [&](int pc, int set) {    // the k right-hand sides at the piece's neighbour site
+    auto load_vectors = [&](int pc, int set, int xs) {    // the k right-hand sides at the piece's neighbour site (xs: XG register set)
       // a y-slab's rows -1 / Ly: the piece's neighbour row comes from the halo buffer ([system][parity][hr][NC]; a row-uniform choice)
       const bool h_hi = pc == 2 && a.halo_hi && y + 1 == a.Ly, h_lo = pc == 4 && a.halo_lo && y == 0;
       const void* vbase = h_hi ? a.halo_hi : h_lo ? a.halo_lo : a.rhs;
       const long vsite = (h_hi || h_lo) ? (long)(1 - p) * a.hr + j : nb_of(pc);
-      auto voff = [&](int k) -> long { return (h_hi || h_lo) ? (long)(a.use_idx ? (int)a.ridx[k] : k) * a.halo_stride : rhs_offset(a, k); };
+      const long vstride = (h_hi || h_lo) ? a.halo_stride : a.vec_stride;
       if constexpr (VL) {                         // lane-linear over [k][c]: element e = g*64 + lane -> (k = e / NC, c = e % NC)
         const long so = vsite * NC;
 #pragma unroll
         for (int g = 0; g < NXG; g++) {
           const int e = g * WAVE + lane;
           const int k = e / NC, c = e - k * NC;
-          XG[g] = (k < nk) ? ldv<V32>(vbase, voff(k) + so + c) : cmake(0.0, 0.0);
+          XG[xs][g] = (k < nk) ? ldv<V32>(vbase, (long)ksys[g] * vstride + so + c) : cmake(0.0, 0.0);
         }
       } else {
-        const long xo = voff(kcol & 15) + vsite * NC;    // B-operand layout straight from global memory
+        const long xo = (long)system_index(a, kcol & 15) * vstride + vsite * NC;    // B-operand layout straight from global memory
 #pragma unroll
         for (int q = 0; q < KS; q++) {
           const int c = 4 * q + lq;
@@ -1037,7 +1067,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         }
       }
     };
-    auto park_piece = [&](int gs) {               // registers -> this wavefront's LDS slice, padded rows
+    auto park_piece = [&](int gs, int xs) {       // registers -> this wavefront's LDS slice, padded rows
       wave_lds_handoff();                         // the previous piece's fragment reads are done
       if (M32) {
 #pragma unroll
@@ -1057,7 +1087,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         for (int g = 0; g < NXG; g++) {
           const int e = g * WAVE + lane;
           const int k = e / NC, c = e - k * NC;
-          if (k < XROWS) xlds[k * XS + c] = XG[g];
+          if (k < XROWS) xlds[k * XS + c] = XG[xs][g];
         }
       }
       wave_lds_handoff();
@@ -1152,18 +1182,31 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       }
     };
 
-    // software pipeline over the five piece slots (activity is uniform over the block).  Slot pc+1 is prefetched while
-    // slot pc computes; a slot whose predecessor is inactive loads on demand.  All register-set indices are
-    // compile-time constants after unrolling.  (VL: the right-hand sides of slot pc are parked with its matrices, so their
-    // registers are free again before slot pc+1 is fetched.)
-    if (act[0]) { load_matrix(0, 0); load_vectors(0, 0); }
+    // software pipeline over the ACTIVE piece slots (activity is uniform over the block): PFD pieces of the matrix stream (XPF of the
+    // right-hand sides) are requested ahead of the piece that computes.  Register-set indices are compile-time constants after unrolling;
+    // requests are issued oldest-needed-first, so the wait in front of a park leaves the younger ones in flight.
+    unsigned am = (act[0] ? 1u : 0u) | (act[1] ? 2u : 0u) | (act[2] ? 4u : 0u) | (act[3] ? 8u : 0u) | (act[4] ? 16u : 0u);
+    const int n = __popc(am);
+    int lst[5];   // the active slots in order (constant indices only: stays in registers)
 #pragma unroll
-    for (int pc = 0; pc < 5; pc++) {
-      if (!act[pc]) continue;
-      if (pc > 0 && !act[pc - 1]) { load_matrix(pc, 0); load_vectors(pc, pc & 1); }
-      park_piece(0);                              // G (and XG) held piece pc; they are free again after this
-      if (pc + 1 < 5 && act[pc + 1]) { load_matrix(pc + 1, 0); load_vectors(pc + 1, (pc + 1) & 1); }
-      mac_piece(pc & 1);
+    for (int i = 0; i < 5; i++) { lst[i] = am ? __ffs(am) - 1 : 0; am &= am - 1; }
+#pragma unroll
+    for (int i = 0; i < PFD; i++)
+      if (i < n) {
+        load_matrix(lst[i], i);
+        if (i == 0 || XPF > 1) load_vectors(lst[i], i & 1, XPF > 1 ? i : 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      if (i < n) {
+        park_piece(i % PFD, XPF > 1 ? i % PFD : 0);   // the sets that held piece i are free again after this
+        if (XPF == 1 && i + 1 < n) load_vectors(lst[i + 1], (i + 1) & 1, 0);
+        if (i + PFD < n) {
+          load_matrix(lst[i + PFD], i % PFD);
+          if (XPF > 1) load_vectors(lst[i + PFD], (i + PFD) & 1, i % PFD);
+        }
+        mac_piece(i & 1);
+      }
     }
 
     // epilogue: shift, accumulate, store.  Lane (lq, lr) owns rows 16 t + 4 i + lq of right-hand side lr.
@@ -1204,7 +1247,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         const int k = e / NC, r = e - k * NC;
         if (k < nk) {
           cplx v = xlds[k * XS + r];
-          const long o = rhs_offset(a, k) + site * NC + r;
+          const long o = (long)ksys[g] * a.vec_stride + site * NC + r;
           if (do_shift) {
             const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
             const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
@@ -1334,8 +1377,8 @@ struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; 
 static thread_local NormWorkspace g_norm_ws;
 namespace qmg {
 void release_stencil_workspace() {   // qmg_shutdown (qmg_runtime.hip)
-  if (g_norm_ws.part) hipFree(g_norm_ws.part);
-  if (g_norm_ws.own) hipFree(g_norm_ws.own);
+  if (g_norm_ws.part) (void)hipFree(g_norm_ws.part);
+  if (g_norm_ws.own) (void)hipFree(g_norm_ws.own);
   g_norm_ws = NormWorkspace();
 }
 }  // namespace qmg

@@ -395,6 +395,8 @@ inline std::vector<inversion_info> bminv_vector_minres_zero_guess(qmg::BatchT<T>
 // ---------------------------------------------------------------------------------------------
 namespace qmg {
 inline bool mr_tolerance_unreachable(double eps) { return eps <= 1e-14; }
+// bgcr_core: the iteration's dots in one pass / one host round trip (see there).  QMG_GCR_FUSED=0 restores the three-pass form.
+inline bool gcr_fused_dots() { static const bool on = !(getenv("QMG_GCR_FUSED") && atoi(getenv("QMG_GCR_FUSED")) == 0); return on; }
 }  // namespace qmg
 template <typename T>
 inline int bmr_fixed_zero_guess(qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T>* r_out, int size, int iters, double omega,
@@ -612,7 +614,30 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
     if (precond) { qmg::bzero(z, size, act); precond(z, r, size, act, precond_info, &pverb); }
     else qmg::bcopy(z, r, size, act);
     matrix_vector(w, z, act, extra_info);
-    if (kb > 0) {
+    // ONE reduction pass and one host round trip per iteration (qmg::gcr_fused_dots(); QMG_GCR_FUSED=0: the three-pass form): the Gram-Schmidt
+    // coefficients c_i = <W_i, w>, <r, w> and <w, w> come from the same pass over the RAW w; for the orthogonalised w' = w - sum_i (c_i / N_i) W_i
+    //   <w', w'> = <w, w> - sum_i |c_i|^2 / N_i          (the W_i are orthogonal)
+    //   <r,  w'> = <r, w>                                (r is orthogonal to every W_i of the cycle: each step removed that component)
+    // A system whose w' keeps less than 1e-6 of |w|^2 (w almost inside the span: the subtraction has lost its digits) takes the explicit dots.
+    std::vector<qmg::cvec> d2(nrhs, qmg::cvec(2, 0.0));
+    unsigned explicit_dots = act;
+    if (qmg::gcr_fused_dots()) {
+      std::vector<qmg::BatchT<T> > basis(W.begin(), W.begin() + kb);
+      basis.push_back(r); basis.push_back(w);
+      std::vector<qmg::cvec> c = qmg::bmultidot(basis, kb + 2, w, size, act);
+      explicit_dots = 0;
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        double ww = c[k][kb + 1].real();
+        const double ww_raw = ww;
+        for (int i = 0; i < kb; i++) { ww -= std::norm(c[k][i]) / Wnorm2[i][k]; c[k][i] = -c[k][i] / Wnorm2[i][k]; }
+        d2[k][0] = c[k][kb]; d2[k][1] = ww;
+        if (!(ww > 1e-6 * ww_raw)) explicit_dots |= 1u << k;
+        c[k].resize(kb);
+        C[k][kb] = c[k];
+      }
+      if (kb > 0) qmg::bmulti_caxpy(c, W, kb, w, size, act);
+    } else if (kb > 0) {
       std::vector<qmg::cvec> c = qmg::bmultidot(W, kb, w, size, act);
       for (int k = 0; k < nrhs; k++)
         if (qmg::is_active(act, k))
@@ -620,10 +645,16 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
       qmg::bmulti_caxpy(c, W, kb, w, size, act);
       for (int k = 0; k < nrhs; k++) if (qmg::is_active(act, k)) C[k][kb] = c[k];
     }
-    rw[0] = r; rw[1] = w;
-    const std::vector<qmg::cvec> d2 = qmg::bmultidot(rw, 2, w, size, act);
+    if (explicit_dots) {
+      rw[0] = r; rw[1] = w;
+      const std::vector<qmg::cvec> e2 = qmg::bmultidot(rw, 2, w, size, explicit_dots);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(explicit_dots, k)) d2[k] = e2[k];
+    }
     qmg::cvec alpha(nrhs, 0.0), malpha(nrhs, 0.0);
     unsigned upd = 0, renorm = 0;
+    // the true norm re-anchors the recurrence when it has lost digits and CONFIRMS a convergence the recurrence announces (fused form; the
+    // three-pass form keeps its wider band of 4 eps)
+    const double band = qmg::gcr_fused_dots() ? 1.0 : 4.0;
     for (int k = 0; k < nrhs; k++) {
       if (!qmg::is_active(act, k)) continue;
       ops[k]++;
@@ -636,7 +667,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
       used[k] = kb + 1;
       upd |= 1u << k;
       rsq[k] = rsq[k] - std::norm(wr) / ww;
-      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < 4.0 * epsv[k] * bnorm[k]) renorm |= 1u << k;
+      if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < band * epsv[k] * bnorm[k]) renorm |= 1u << k;
     }
     qmg::bcaxpy(malpha, w, r, size, upd);
     if (renorm) {
