@@ -615,10 +615,12 @@ def kcycle_c3(extra_env=None):
         return {"error": repr(e)}
 
 
-def kcycle_c3_batched(nrhs=8):
+def kcycle_c3_batched(nrhs=8, f32=False):
     """The same solve for a lock-step batch of `nrhs` independent right-hand sides on the one GPU (include/qmg/batch.hpp):
     coarse operators / null vectors streamed once per step for the batch, coarse applies on the f64 matrix cores.
-    `value` is the aggregate over the batch (sum of the systems' outer iterations / wall)."""
+    `value` is the aggregate over the batch (sum of the systems' outer iterations / wall).
+    f32: the K-cycle preconditioner entirely in complex<float> (vectors, matrices, null vectors) inside the fp64 outer VPGCR, which
+    still converges to 1e-10 in fp64 (mg_preconditioner_batch_mixed)."""
     import re
     import subprocess
     drivers = os.path.join(ROOT, "quantum-mg_amd", "drivers")
@@ -627,11 +629,12 @@ def kcycle_c3_batched(nrhs=8):
     try:
         if not os.path.exists(exe):
             subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
-        p = subprocess.run([exe, "2048", str(MASS), "6.0", "2", "24", fixture, "64", str(nrhs)], cwd=drivers, env=dict(os.environ, QMG_QUIET="1"),
-                           capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, "2048", str(MASS), "6.0", "2", "24", fixture, "64", str(nrhs)] + (["f32"] if f32 else []), cwd=drivers,
+                           env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=600)
         m = re.search(r"setup ([\d.e+-]+) s ; batched solve of (\d+) systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+) ; systems/s ([\d.e+-]+)", p.stdout)
         rows = re.findall(r"rhs (\d+) (converged|failed to converge) in (\d+) iterations ; alleged tolerance [\d.e+-]+ ; check tolerance ([\d.e+-]+)", p.stdout)
-        return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, fp64, %d independent right-hand sides in lock step on 1 GPU" % nrhs,
+        return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, %s, %d independent right-hand side%s%s on 1 GPU"
+                            % ("K-cycle in complex<float> inside the fp64 outer solve" if f32 else "fp64", nrhs, "s" if nrhs > 1 else "", " in lock step" if nrhs > 1 else ""),
                 "metric": "aggregate outer VPGCR iterations per second", "value": float(m.group(4)), "systems_per_s": float(m.group(5)),
                 "solve_s": float(m.group(3)), "setup_s": float(m.group(1)), "nrhs": nrhs,
                 "outer_iterations": [int(r[2]) for r in rows], "all_converged": all(r[1] == "converged" for r in rows) and len(rows) == nrhs,
@@ -909,6 +912,12 @@ def main():
         out["also_kcycle_c5_schur"] = kcycle_c5_schur_and_f32()
         out["also_kcycle_strict_fp64"] = kcycle_c3_strict_fp64()
         out["also_kcycle_batched"] = kcycle_c3_batched()
+        # the same configuration with the K-cycle in complex<float> (the outer solve, its tolerance and the residual check stay fp64): one system, then 8
+        f1, f8 = kcycle_c3_batched(1, f32=True), kcycle_c3_batched(8, f32=True)
+        out["also_kcycle"]["fp32_kcycle"] = f1
+        if "value" in f1 and "value" in out["also_kcycle"]:
+            out["also_kcycle"]["fp32_over_fp64"] = f1["value"] / out["also_kcycle"]["value"]
+        out["also_kcycle_batched"]["fp32_kcycle"] = f8
         out["also_kcycle_c5_shape"] = kcycle_c5_shape()
 
     if not args.no_also:   # every rank takes part: the slabs of one lattice

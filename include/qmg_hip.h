@@ -252,10 +252,11 @@ int qmg_batch_blas(int op, const double* a, const double* b, const void* x, cons
 int qmg_batch_multi_caxpy(const double* coeffs, const void* const* xs, int nj, void* y, size_t n,
                           int nrhs, size_t stride, unsigned mask, void* stream);
 typedef enum { QMG_BRED_NORM2 = 0, QMG_BRED_DOT = 1, QMG_BRED_DIFFNORM2 = 2 } qmg_batch_red;
-/* out_host[2k], out_host[2k+1] for each active system k; synchronises the stream */
+/* out_host[2k], out_host[2k+1] for each active system k; returns when the results are on the host (tuning key "reduce_spin": by polling a
+ * host word behind them, the stream itself is then not synchronised; 0: hipStreamSynchronize) */
 int qmg_batch_reduce(int op, const void* x, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
                      double* out_host, void* stream);
-/* out_host[(k*nj + j)*2 + {0,1}] = <xs[j]_k, y_k>, nj <= 32; synchronises the stream */
+/* out_host[(k*nj + j)*2 + {0,1}] = <xs[j]_k, y_k>, nj <= 32; returns when the results are on the host (as qmg_batch_reduce) */
 int qmg_batch_multidot(const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
                        double* out_host, void* stream);
 /* transfer.h:455-511 for the batch: the nvec null vectors are read once per 8 active systems */
@@ -441,6 +442,9 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *                   0: the full-lattice restrict / prolong / probe passes of the reference's formulation (1)
  *   "malloc_poison" 1: qmg_malloc fills every allocation with 0xFF bytes (NaNs in every storage precision): a buffer read before
  *                   it is written then shows deterministically (0)
+ *   "reduce_spin"   1: the host picks the results of the batch reductions (qmg_batch_reduce*, qmg_batch_multidot*) up by polling a sequence
+ *                   number the final stage's last block publishes in coherent host memory behind them; the stream is NOT synchronised by
+ *                   these calls then (later launches are ordered behind the kernel anyway).  0: hipStreamSynchronize, as before (1)
  * (The ablation switch of tools/variants.py exists only in the tools build, `make DIAG=1`; this library has no such key.) */
 /* (QMG_TUNING="key=value,key=value" in the environment applies the same settings inside qmg_init -- for A/B runs of programs that do not call this.) */
 int qmg_set_tuning(const char* key, int value);

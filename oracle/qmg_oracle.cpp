@@ -180,6 +180,22 @@ int qo_cshift(double* lhs, const double* rhs, int cdir, int eo, int dof, int Lx,
 //   oe: 4 x {cshift FROM_EVEN, cMATxpy on odd half} (:787-801) ; shifts (:865-909).
 int qo_stencil_apply(const qo_stencil_desc* d, double* lhs_, const double* rhs_, unsigned pieces) {
   const int Lx = d->Lx, Ly = d->Ly, nc = d->nc;
+  if (Lx == 1 && Ly == 1 && nc >= 1) {
+    // volume == 1 (stencil_2d.h:870-888): every half-volume loop of the clover / hopping passes runs 0 times (their counts are volume / 2), so
+    // only apply_M_shift acts, in its corner form: the site counts as even
+    cplx* l = C(lhs_);
+    const cplx* r = C(rhs_);
+    const cplx sh(d->shift[0], d->shift[1]), eo(d->eo_shift[0], d->eo_shift[1]), ds(d->dof_shift[0], d->dof_shift[1]);
+    if (pieces & (QO_P_ZERO_E | QO_P_ZERO_O)) for (int c = 0; c < nc; c++) l[c] = 0.0;
+    if (pieces & QO_P_SHIFT_E) {
+      if (nc % 2 == 0) {
+        for (int c = 0; c < nc / 2; c++) { l[c] += (sh + eo + ds) * r[c]; l[c + nc / 2] += (sh + eo - ds) * r[c + nc / 2]; }
+      } else {
+        for (int c = 0; c < nc; c++) l[c] += (sh + eo) * r[c];
+      }
+    }
+    return 0;
+  }
   if (Lx < 2 || Ly < 2 || (Lx & 1) || (Ly & 1) || nc < 1) return -1;
   const long vol = (long)Lx * Ly, half_vol = vol / 2;
   const long size_cv = vol * nc, half_cv = size_cv / 2;

@@ -107,6 +107,17 @@ def sync(stream=None):
     check(lib().qmg_stream_sync(C.c_void_p(stream)), "qmg_stream_sync")
 
 
+def stream_create():
+    """A non-default HIP stream as the raw handle every `stream=` argument takes."""
+    st = C.c_void_p()
+    check(lib().qmg_stream_create(C.byref(st)), "qmg_stream_create")
+    return st.value
+
+
+def stream_destroy(stream):
+    check(lib().qmg_stream_destroy(C.c_void_p(stream)), "qmg_stream_destroy")
+
+
 class DeviceArray:
     """A complex128 (or raw bytes) array in HBM owned through qmg_malloc / qmg_free."""
 

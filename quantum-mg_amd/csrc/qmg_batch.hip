@@ -464,7 +464,7 @@ int qmg_batch_multi_caxpy(const double* coeffs, const void* const* xs, int nj, v
   return qmg_batch_multi_caxpy_t(QMG_C64, coeffs, xs, nj, y, n, nrhs, stride, mask, stream);
 }
 
-// out_host[2*k + {0,1}] for every ACTIVE system k (inactive entries are left untouched); synchronises the stream
+// out_host[2*k + {0,1}] for every ACTIVE system k (inactive entries are left untouched); returns when they are on the host (wait_results)
 int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n, int nrhs, size_t stride, unsigned mask, double* out_host, void* stream) {
   if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || !x || !out_host) return QMG_ERR_INVALID;
   if (op < QMG_BRED_NORM2 || op > QMG_BRED_DIFFNORM2) return QMG_ERR_INVALID;
@@ -507,7 +507,7 @@ int qmg_batch_reduce(int op, const void* x, const void* y, size_t n, int nrhs, s
   return qmg_batch_reduce_t(QMG_C64, op, x, y, n, nrhs, stride, mask, out_host, stream);
 }
 
-// out_host[(k*nj + j)*2 + {0,1}] = <xs[j]_k , y_k> for every active system k; synchronises the stream
+// out_host[(k*nj + j)*2 + {0,1}] = <xs[j]_k , y_k> for every active system k; returns when they are on the host (wait_results)
 int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask, double* out_host,
                          void* stream) {
   if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || nj < 1 || nj > BDOT_MAX || !xs || !y || !out_host) return QMG_ERR_INVALID;

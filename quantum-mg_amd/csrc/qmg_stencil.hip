@@ -1373,12 +1373,16 @@ extern "C" int qmg_stencil_apply_epi_t(int dtype, int mat32, const qmg_stencil_d
 }
 
 // partials of the fused norms (one buffer per host thread = per rank, grown on demand) and the default result slot
-struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; double* own = nullptr; int own_dev = -1; };
+// part: the fused-norm partials of the calling thread.  One buffer per thread, so two calls of one thread on DIFFERENT streams would race on it:
+// `done` is recorded behind every use and a call on another stream than the last one waits for it first (same stream: stream order suffices).
+struct NormWorkspace { double* part = nullptr; size_t cap = 0; int device = -1; double* own = nullptr; int own_dev = -1;
+                       hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false; };
 static thread_local NormWorkspace g_norm_ws;
 namespace qmg {
 void release_stencil_workspace() {   // qmg_shutdown (qmg_runtime.hip)
   if (g_norm_ws.part) (void)hipFree(g_norm_ws.part);
   if (g_norm_ws.own) (void)hipFree(g_norm_ws.own);
+  if (g_norm_ws.done) (void)hipEventDestroy(g_norm_ws.done);
   g_norm_ws = NormWorkspace();
 }
 }  // namespace qmg
@@ -1477,9 +1481,55 @@ extern "C" int qmg_stencil_apply_t(int dtype, const qmg_stencil_desc* d, void* l
 #define QMG_EPI_FINISH()                                                                        \
   if (epi_npart) { const unsigned char id0 = a.ridx[0]; const int erc = mr_epilogue_finish(&id0, 1, epi_npart, st); if (erc) return erc; }
 
+// The 1 x 1 lattice (lattice.h:77,201; stencil_2d.h:870-888, "this corner case is annoying").  Every half-volume loop of the reference runs
+// volume / 2 = 0 times there -- the clover sweeps, the cshifts and the hopping cMATxpy's touch nothing -- so apply_M is its shift term alone:
+// the one site counts as even, lhs[c] += (shift + eo_shift +- dof_shift) rhs[c] (dof_shift only for even nc, + on the first half).
+// The zero pieces clear the site.  One tiny launch; plain applies only.
+template <typename T>
+__global__ void k_stencil_volume1(void* lhs_, const void* rhs_, int nc, int nrhs, long stride, const unsigned char* ridx_dev_unused, StencilArgs a, int zero, int shift_on) {
+  typedef typename CStore<T>::type ct;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc * nrhs) return;
+  const int k = i / nc, c = i - k * nc;
+  const long o = (long)(a.use_idx ? (int)a.ridx[k] : k) * stride + c;
+  ct* lhs = reinterpret_cast<ct*>(lhs_);
+  const ct* rhs = reinterpret_cast<const ct*>(rhs_);
+  cplx v = cmake(0.0, 0.0);
+  if (!zero) { const ct l = lhs[o]; v = cmake((double)l.x, (double)l.y); }
+  if (shift_on) {
+    const double dg = (nc % 2 == 0) ? ((c < nc / 2) ? 1.0 : -1.0) : 0.0;
+    const cplx sh = cmake(a.shift[0] + a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + a.eo_shift[1] + dg * a.dof_shift[1]);
+    const ct r = rhs[o];
+    cmac(v, sh, cmake((double)r.x, (double)r.y));
+  }
+  ct w; w.x = (T)v.x; w.y = (T)v.y;
+  lhs[o] = w;
+}
+
+static int stencil_apply_volume1(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
+                                 const unsigned char* ridx, void* stream, int vec32) {
+  if (d->nc < 1 || nrhs > 16 || (nrhs > 1 && vec_stride < (size_t)d->nc)) return QMG_ERR_INVALID;
+  StencilArgs a;
+  memset(&a, 0, sizeof(a));
+  a.use_idx = ridx ? 1 : 0;
+  for (int k = 0; k < 16; k++) a.ridx[k] = ridx ? ridx[k < nrhs ? k : 0] : (unsigned char)k;
+  for (int i = 0; i < 2; i++) { a.shift[i] = d->shift[i]; a.eo_shift[i] = d->eo_shift[i]; a.dof_shift[i] = d->dof_shift[i]; }
+  const int zero = (pieces & (QMG_P_ZERO_E | QMG_P_ZERO_O)) ? 1 : 0, shift_on = (pieces & QMG_P_SHIFT_E) ? 1 : 0;
+  if (!zero && !shift_on) return QMG_SUCCESS;
+  const int n = d->nc * nrhs;
+  if (vec32) k_stencil_volume1<float><<<(n + 63) / 64, 64, 0, as_stream(stream)>>>(lhs, rhs, d->nc, nrhs, (long)vec_stride, nullptr, a, zero, shift_on);
+  else k_stencil_volume1<double><<<(n + 63) / 64, 64, 0, as_stream(stream)>>>(lhs, rhs, d->nc, nrhs, (long)vec_stride, nullptr, a, zero, shift_on);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
 static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int nrhs, size_t vec_stride,
                               const unsigned char* ridx, void* stream, int mat32, int vec32, const SlabHalo* slab, double* norms_dev, const qmg_apply_epilogue* epi) {
   if (!d || !lhs || !rhs || nrhs < 1) return QMG_ERR_INVALID;
+  if (d->Lx == 1 && d->Ly == 1) {
+    if (slab || norms_dev || epi) return QMG_ERR_UNSUPPORTED;
+    return stencil_apply_volume1(d, lhs, rhs, pieces, nrhs, vec_stride, ridx, stream, vec32);
+  }
   if (!valid_lattice(d->Lx, d->Ly) || d->nc < 1) return QMG_ERR_INVALID;
   const int nc = d->nc;
   if (nrhs > 1 && vec_stride < (size_t)d->Lx * d->Ly * nc) return QMG_ERR_INVALID;
@@ -1545,10 +1595,14 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     if (ws.device != dev || ws.cap < (size_t)nparts * nrhs) {
       if (ws.part && ws.device == dev) QMG_HIP_CHECK(hipFree(ws.part));   // (synchronises: no launch still writes the old buffer)
       ws.part = nullptr; ws.cap = 0;
+      if (ws.device != dev && ws.done) { (void)hipEventDestroy(ws.done); ws.done = nullptr; }   // (an event belongs to the device it was created on)
+      ws.used = false;
       QMG_HIP_CHECK(hipMalloc((void**)&ws.part, sizeof(double) * (size_t)nparts * nrhs));
       ws.cap = (size_t)nparts * nrhs; ws.device = dev;
     }
     a.norm_part = ws.part;
+    if (!ws.done) QMG_HIP_CHECK(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    if (ws.used && ws.last != st) QMG_HIP_CHECK(hipStreamWaitEvent(st, ws.done, 0));   // the previous call's partials are still being summed on another stream
     dim3 grid(gx, gyp), block(BLOCK);
     const bool pf = nc == 1 && nrhs > 1 && g_pair_prefetch;   // (nc = 2: the prefetch costs 3 %, tools/apply_norm_ab.py)
 #define QMG_NORM_LAUNCH(NC, ROWS, PF) k_stencil_pair<double, NC, ROWS, true, true, true, PF><<<grid, block, smem, st>>>(a);
@@ -1560,6 +1614,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
     QMG_LAUNCH_CHECK();
     k_apply_norm_final<<<nrhs, BLOCK, 0, st>>>(ws.part, nparts, norms_dev);
     QMG_LAUNCH_CHECK();
+    QMG_HIP_CHECK(hipEventRecord(ws.done, st));
+    ws.last = st; ws.used = true;
     return QMG_SUCCESS;
   }
 

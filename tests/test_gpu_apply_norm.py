@@ -87,6 +87,36 @@ def test_apply_norm2_device_result_staggered_shape():
         assert abs(got[k] - exact) <= 1e-13 * exact
 
 
+def test_apply_norm2_on_two_streams_of_one_thread():
+    """The fused-norm partials live in ONE buffer per calling thread: calls that alternate between two streams must not overlap on it (the library
+    orders them with an event).  Two operators of different size, 24 alternating launches with device-resident results and no host
+    synchronisation in between; every result must be the one the same call gives alone."""
+    s1, s2 = qmg.stream_create(), qmg.stream_create()
+    try:
+        ops = []
+        for L, nc, nrhs, seed in ((64, 2, 4, 31), (48, 1, 8, 41)):
+            vol = L * L
+            clover = cs.gaussian_cvec(vol * nc * nc, seed) if nc == 2 else None
+            hopping = cs.gaussian_cvec(4 * vol * nc * nc, seed + 1)
+            gd = qmg.make_desc(L, L, nc, D(clover) if clover is not None else None, D(hopping), 0.1)
+            rhs = D(cs.gaussian_cvec(vol * nc * nrhs, seed + 2))
+            lhs = qmg.DeviceArray.zeros(vol * nc * nrhs)
+            alone = qmg.stencil_apply_norm2(gd, lhs, rhs, ol.P_ALL | ol.P_ZERO, nrhs, vol * nc)
+            outs = [D(np.zeros(nrhs // 2 + nrhs % 2, dtype=np.complex128)) for _ in range(12)]
+            ops.append((gd, lhs, rhs, nrhs, vol * nc, alone, outs))
+        for i in range(12):
+            for (gd, lhs, rhs, nrhs, stride, alone, outs), st in zip(ops, (s1, s2)):
+                qmg.stencil_apply_norm2(gd, lhs, rhs, ol.P_ALL | ol.P_ZERO, nrhs, stride, norms_dev=outs[i].ptr, stream=st)
+        qmg.sync(s1)
+        qmg.sync(s2)
+        for gd, lhs, rhs, nrhs, stride, alone, outs in ops:
+            for o in outs:
+                assert np.array_equal(o.to_host().view(np.float64)[:nrhs], np.asarray(alone)), (nrhs, o.to_host(), alone)
+    finally:
+        qmg.stream_destroy(s1)
+        qmg.stream_destroy(s2)
+
+
 def test_apply_norm2_refusals():
     Lx, Ly = 12, 6
     for nc in (1, 4):

@@ -195,6 +195,37 @@ def test_minimum_lattices(Lx, Ly, nc):
         assert cs.rel_l2(got, want) < TOL, pieces
 
 
+@pytest.mark.parametrize("nc", [1, 2, 3, 8])
+def test_volume_one_lattice(nc):
+    """lattice.h:77,201 / stencil_2d.h:870-888: on the 1 x 1 lattice every half-volume loop of the reference (clover sweeps, cshifts, hopping
+    products: counts volume / 2 = 0) touches nothing, so apply_M is the shift term in its corner form -- the one site counts as even,
+    lhs[c] += (shift + eo_shift +- dof_shift) rhs[c] with the dof term for even nc only.  Device against the oracle and against the formula;
+    the stored matrices must not matter."""
+    clover, hopping = cs.gaussian_cvec(nc * nc, 1), cs.gaussian_cvec(4 * nc * nc, 2)
+    rhs, lhs0 = cs.gaussian_cvec(nc, 3), cs.gaussian_cvec(nc, 4)
+    sh, eo, ds = 0.3 - 0.1j, 0.05 + 0.02j, 0.7 + 0.4j
+    fac = np.full(nc, sh + eo, dtype=np.complex128)
+    if nc % 2 == 0:
+        fac[:nc // 2] += ds
+        fac[nc // 2:] -= ds
+    for pieces, want in ((ol.P_ALL | ol.P_ZERO, fac * rhs), (ol.P_ALL, lhs0 + fac * rhs), (ol.P_HOPPING | ol.P_CLOVER, lhs0), (ol.P_SHIFT | ol.P_ZERO, fac * rhs),
+                         (ol.P_ZERO, np.zeros(nc))):
+        w, g = _apply_both(1, 1, nc, clover, hopping, rhs, pieces, (sh, eo, ds), lhs0)
+        assert np.array_equal(w, want) or cs.rel_l2(w, want) < 1e-15, pieces
+        assert np.allclose(g, w, rtol=4e-16, atol=1e-300), (pieces, g, w)
+    # a batch of three systems with a gap in the mask, both storage precisions
+    X = cs.gaussian_cvec(3 * nc, 5)
+    out = D(np.zeros(3 * nc))
+    gd = qmg.make_desc(1, 1, nc, None, None, sh, eo, ds)
+    qmg.stencil_apply_batch(gd, out, D(X), ol.P_ALL | ol.P_ZERO, 3, nc, 0b101)
+    got = out.to_host().reshape(3, nc)
+    assert np.allclose(got[0], fac * X[:nc], rtol=4e-16) and np.allclose(got[2], fac * X[2 * nc:], rtol=4e-16) and np.all(got[1] == 0)
+    x32 = qmg.DeviceArray.from_host(X.astype(np.complex64))
+    o32 = qmg.DeviceArray.from_host(np.zeros(3 * nc, dtype=np.complex64))
+    qmg.stencil_apply_t(qmg.C32, gd, o32, x32, ol.P_ALL | ol.P_ZERO, nrhs=3, vec_stride=nc, mask=0b111)
+    assert np.allclose(o32.to_host(), (np.tile(fac, 3) * X).astype(np.complex64), rtol=3e-7)
+
+
 def test_zero_length_and_strided_inputs():
     """Empty inputs are accepted and do nothing; multi-RHS batches may be padded (vec_stride > size_cv)."""
     import ctypes as C

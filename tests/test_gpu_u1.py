@@ -114,15 +114,19 @@ def test_heatbath_is_reproducible_and_layout_independent():
     assert not np.array_equal(a.to_host(), b.to_host())
 
 
-def test_n15_pion_mass_matches_the_reference_table(tmp_path):
-    """tests/n15_wilson_goldstone_u1_heatbath/critical_mass.txt:8: 32^2, beta = 6.0, m = +0.01 -> m_pi = 0.28205(47).
+@pytest.mark.parametrize("mass,m_pi_ref", [(0.01, 0.28205), (-0.01, 0.23957)])
+def test_n15_pion_mass_matches_the_reference_table(tmp_path, mass, m_pi_ref):
+    """tests/n15_wilson_goldstone_u1_heatbath/critical_mass.txt:8-9: 32^2, beta = 6.0, m = +0.01 -> m_pi = 0.28205(47), m = -0.01 -> 0.23957(53).
     The counterpart driver: device heatbath (100 sweeps between measurements, as n15:55), two BiCGStab-6 inversions per
     configuration, correlator through qmg_norm2sq_cv_timeslice.  400 configurations, cosh fit over t = 7..16 of the folded
     correlator; the band also has to absorb the fit-window choice, so +-0.012 -- which still separates the table's neighbouring masses
-    (m = -0.01: 0.23957, a 0.042 step)."""
+    (a 0.042 step).  Why not tighter, and why not the rows nearer the critical mass: the Wilson correlator's distribution is heavy-tailed
+    there (near-zero modes on single configurations), and 400 configurations leave the fit +-0.007 (m = -0.01) to +-0.1 (m = -0.05) -- all
+    five rows measured in profiles/r03_pion_table.txt; the table's 5e-4 needs the reference author's (unrecorded) statistics.  The
+    staggered table below has no such tail and is held to +-0.006 on every row."""
     from scipy.optimize import curve_fit
     cfg = str(tmp_path / "last.dat")
-    out = subprocess.run([os.path.join(DRIVERS, "n15_wilson_goldstone_u1_heatbath"), "32", "0.01", "6.0", "400", "100", "1000", "1337", cfg], cwd=DRIVERS,
+    out = subprocess.run([os.path.join(DRIVERS, "n15_wilson_goldstone_u1_heatbath"), "32", str(mass), "6.0", "400", "100", "1000", "1337", cfg], cwd=DRIVERS,
                          env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "400 measurements, 0 unconverged" in out.stdout
@@ -135,10 +139,10 @@ def test_n15_pion_mass_matches_the_reference_table(tmp_path):
     assert len(t) == 32 and np.all(c > 0)
     sel = (t >= 7) & (t <= 16)                                   # the folded correlator: A cosh(m (t - T/2))
     (amp, m_pi), cov = curve_fit(lambda tt, a, m: a * np.cosh(m * (tt - 16.0)), t[sel], c[sel], p0=(c[16], 0.3), sigma=dc[sel], absolute_sigma=True)
-    assert abs(m_pi - 0.28205) < 0.012, (m_pi, np.sqrt(cov[1, 1]))
+    assert abs(m_pi - m_pi_ref) < 0.012, (m_pi, np.sqrt(cov[1, 1]))
     # and the reference's own estimator (n15:211-216), averaged over the plateau
     eff = np.array([np.arccosh((c[j + 1] + c[j - 1]) / (2.0 * c[j])) for j in range(8, 15)])
-    assert abs(np.nanmean(eff) - 0.28205) < 0.02, eff
+    assert abs(np.nanmean(eff) - m_pi_ref) < 0.02, eff
     # the written configuration is in the reference's format: 2 L^2 phases, one per line, in (-pi, pi]
     ph = np.loadtxt(cfg)
     assert ph.shape == (2 * 32 * 32,) and np.all(np.abs(ph) <= np.pi)
@@ -146,12 +150,14 @@ def test_n15_pion_mass_matches_the_reference_table(tmp_path):
     assert abs(qmg.u1_plaquette(qmg.DeviceArray.from_host(g), 32, 32)[0] - np_plaquette(Ux, Uy)[0]) < 1e-13
 
 
-@pytest.mark.parametrize("mass,m_pi_ref", [(0.1, 0.355891), (0.04, 0.202947)])
+@pytest.mark.parametrize("mass,m_pi_ref", [(0.1, 0.355891), (0.08, 0.308843), (0.06, 0.258516), (0.04, 0.202947)])
 def test_n20_staggered_pion_mass_matches_the_reference_table(mass, m_pi_ref):
-    """tests/n20_staggered_goldstone_u1_heatbath/critical_mass.txt:4,7: 32^2, beta = 6.0, m = 0.1 -> m_pi = 0.355891(41), m = 0.04 ->
-    0.202947(55).  The counterpart driver (device heatbath, one BiCGStab-6 staggered inversion per configuration, Goldstone correlator
-    through qmg_norm2sq_cv_timeslice), 400 configurations, cosh fit over t = 7..16 of the folded correlator.  The band (+-0.012) absorbs
-    statistics and the fit window and still separates the table's neighbouring masses (steps of 0.047 - 0.056)."""
+    """tests/n20_staggered_goldstone_u1_heatbath/critical_mass.txt:4-7, EVERY row: 32^2, beta = 6.0, m = 0.1 / 0.08 / 0.06 / 0.04 -> m_pi =
+    0.355891(41) / 0.308843(42) / 0.258516(48) / 0.202947(55).  The counterpart driver (device heatbath, one BiCGStab-6 staggered inversion
+    per configuration, Goldstone correlator through qmg_norm2sq_cv_timeslice), 400 configurations, cosh fit over t = 7..16 of the folded
+    correlator.  Measured (profiles/r03_pion_table.txt): 0.35744(228) / 0.31023(254) / 0.25985(298) / 0.20385(387), i.e. 0.9e-3 - 1.6e-3 from
+    the table with a fit-window spread of 1.5e-3; the band is +-0.006 (twice the statistical error of the worst row), an eighth of the
+    table's step between neighbouring masses."""
     from scipy.optimize import curve_fit
     out = subprocess.run([os.path.join(DRIVERS, "n20_staggered_goldstone_u1_heatbath"), "32", str(mass), "6.0", "400", "100", "1000", "1337"], cwd=DRIVERS,
                          env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=900)
@@ -164,4 +170,4 @@ def test_n20_staggered_pion_mass_matches_the_reference_table(mass, m_pi_ref):
     assert len(t) == 32 and np.all(c > 0)
     sel = (t >= 7) & (t <= 16)
     (amp, m_pi), cov = curve_fit(lambda tt, a, m: a * np.cosh(m * (tt - 16.0)), t[sel], c[sel], p0=(c[16], 0.3), sigma=dc[sel], absolute_sigma=True)
-    assert abs(m_pi - m_pi_ref) < 0.012, (mass, m_pi, np.sqrt(cov[1, 1]))
+    assert abs(m_pi - m_pi_ref) < 0.006, (mass, m_pi, np.sqrt(cov[1, 1]))

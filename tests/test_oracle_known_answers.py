@@ -257,3 +257,24 @@ def test_redot_timeslice_and_wall_source():
     vals = np.concatenate([cs.eo_to_grid(ol.gaussian_wall_source(Lx, Ly, nc, t, 1, 7 + t, deviation=2.0, mean=0.5), Lx, Ly, nc)[:, t, 1].real for t in range(Ly)])
     assert abs(vals.mean() - 0.5) < 0.15 and abs(vals.std() - 2.0) < 0.15          # 2048 draws
     assert ol.gaussian_wall_source(Lx, Ly, nc, Ly, 0, 1) is None and ol.gaussian_wall_source(Lx, Ly, nc, 0, nc, 1) is None
+
+
+def test_volume_one_lattice_is_the_shift_corner_case():
+    """stencil_2d.h:870-888 on the oracle: a 1 x 1 lattice applies lhs[c] += (shift + eo_shift +- dof_shift) rhs[c] and nothing else (every
+    half-volume loop of the clover / hopping passes has count volume / 2 = 0)."""
+    for nc in (1, 2, 3, 8):
+        rng = np.random.default_rng(nc)
+        clover = (rng.normal(size=nc * nc) + 1j * rng.normal(size=nc * nc)).astype(np.complex128)
+        hopping = (rng.normal(size=4 * nc * nc) + 1j * rng.normal(size=4 * nc * nc)).astype(np.complex128)
+        rhs = (rng.normal(size=nc) + 1j * rng.normal(size=nc)).astype(np.complex128)
+        sh, eo, ds = 0.3 - 0.1j, 0.05 + 0.02j, 0.7 + 0.4j
+        d = ol.make_desc(1, 1, nc, clover, hopping, sh, eo, ds)
+        fac = np.full(nc, sh + eo, dtype=np.complex128)
+        if nc % 2 == 0:
+            fac[:nc // 2] += ds
+            fac[nc // 2:] -= ds
+        out = ol.stencil_apply(d, rhs, ol.P_ALL | ol.P_ZERO)
+        assert np.allclose(out, fac * rhs, rtol=1e-15)
+        lhs = rhs.copy()
+        ol.stencil_apply(d, rhs, ol.P_CLOVER | ol.P_HOPPING, lhs=lhs)
+        assert np.array_equal(lhs, rhs)

@@ -26,10 +26,18 @@ python tools/solve_phase_profile.py $O/prof_n13 > $O/${TAG}_n13_solve_phase.json
 rm -rf $O/prof_n13
 echo n13 done
 QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_n22 -- quantum-mg_amd/drivers/n22_wilson_kcycle_adaptive 4096 -0.07 6.0 3 1 tests/golden/l64t64b60_heatbath.dat 64 schur nrhs=1 f32 > $O/${TAG}_n22_c5_schur_f32.log 2>&1
-python tools/solve_phase_profile.py $O/prof_n22 > $O/${TAG}_n22_c5_schur_f32_solve_phase.json
+python tools/solve_phase_profile.py $O/prof_n22 last > $O/${TAG}_n22_c5_schur_f32_solve_phase.json
 rm -rf $O/prof_n22
 echo n22 done
+for v in "" f32; do
+  rm -rf $O/prof_m
+  QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_m -- quantum-mg_amd/drivers/n13_wilson_kcycle_mrhs 2048 -0.07 6.0 2 24 tests/golden/l64t64b60_heatbath.dat 64 8 $v > $O/${TAG}_n13_mrhs8${v:+_}$v.log 2>&1
+  python tools/solve_phase_profile.py $O/prof_m > $O/${TAG}_n13_mrhs8${v:+_}${v}_solve_phase.json
+  rm -rf $O/prof_m
+done
+echo mrhs done
 python tools/xfer_bench.py > $O/${TAG}_xfer_mfma.txt 2>&1
+python tools/kernelc_bench.py > $O/${TAG}_kernelC_multi_rhs.txt 2>&1
 echo xfer done
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 echo bench done

@@ -12,6 +12,6 @@ python tools/solve_phase_profile.py $O/prof_n13 > $O/${TAG}_n13_solve_phase.json
 rm -rf $O/prof_n13
 echo n13 done
 QMG_QUIET=1 rocprofv3 --kernel-trace --output-format csv -d $O/prof_n22 -- quantum-mg_amd/drivers/n22_wilson_kcycle_adaptive 4096 -0.07 6.0 3 1 $F 64 schur nrhs=1 f32 > $O/${TAG}_n22_c5_schur_f32.log 2>&1
-python tools/solve_phase_profile.py $O/prof_n22 > $O/${TAG}_n22_c5_schur_f32_solve_phase.json
+python tools/solve_phase_profile.py $O/prof_n22 last > $O/${TAG}_n22_c5_schur_f32_solve_phase.json
 rm -rf $O/prof_n22
 echo n22 done

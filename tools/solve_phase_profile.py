@@ -1,11 +1,15 @@
 """Split a rocprofv3 --kernel-trace of a K-cycle driver (n13/n19) into setup and solve and summarise the SOLVE phase:
 per-kernel totals, GPU busy time vs wall time (the gap is launch / host-sync latency), and launches per outer iteration.
 
-The solve starts after the last setup-only kernel (Galerkin probes / block-orthonormalisation leaves).  The full
-trace is too large to carry back from the GPU box, so this runs there and writes a small JSON:
+The solve starts after the last setup-only kernel (Galerkin probes / block-orthonormalisation leaves).  What follows is cut into
+SEGMENTS at every gap longer than 5 ms -- no launch or reduction round trip takes that long; such a gap is host work between phases: the
+scratch reservation in front of a timed solve (GB-sized hipMallocs: 3 ms or 1.6 s on this pool), the creation of the fp32
+shadow hierarchy between the two solves of the n22 driver -- and ONE segment is reported as "solve": the one with the most GPU time
+(default) or the last one (`last`: the fp32 solve of `n22 ... f32`, which runs after the fp64 one).  Every segment is listed, so nothing
+is hidden.  The full trace is too large to carry back from the GPU box, so this runs there and writes a small JSON:
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_n13 -- quantum-mg_amd/drivers/n13_wilson_kcycle ...
-    python tools/solve_phase_profile.py gpurun_out/prof_n13 > gpurun_out/n13_solve_phase.json
+    python tools/solve_phase_profile.py gpurun_out/prof_n13 [largest|last] > gpurun_out/n13_solve_phase.json
 """
 import csv
 import glob
@@ -59,6 +63,31 @@ def summarise(rs):
             "kernels": [{"kernel": k, "calls": v[0], "total_ms": v[1] / 1e6, "avg_us": v[1] / v[0] / 1e3, "pct_of_wall": 100.0 * v[1] / wall} for k, v in top[:24]]}
 
 
-out = {"trace": os.path.basename(f), "setup": summarise(rows[:last_setup + 1]), "solve": summarise(solve)}
+which = sys.argv[2] if len(sys.argv) > 2 else "largest"
+segs, cur = [], []
+for r in solve:
+    if cur and r[0] - max(x[1] for x in cur[-8:]) > 5_000_000:
+        segs.append(cur)
+        cur = []
+    cur.append(r)
+if cur:
+    segs.append(cur)
+
+
+def busy_of(rs):
+    b, ce = 0, rs[0][0]
+    for s_, e_, _ in rs:
+        if e_ > ce:
+            b += e_ - max(s_, ce)
+            ce = e_
+    return b
+
+
+seg_info = [{"launches": len(g), "wall_ms": (g[-1][1] - g[0][0]) / 1e6, "gpu_busy_ms": busy_of(g) / 1e6,
+             "gap_before_ms": (g[0][0] - segs[i - 1][-1][1]) / 1e6 if i else 0.0} for i, g in enumerate(segs)]
+pick = len(segs) - 1 if which == "last" else max(range(len(segs)), key=lambda i: seg_info[i]["gpu_busy_ms"]) if segs else 0
+# ("last": the driver's closing residual check is a handful of launches right behind the solve, inside the same segment)
+out = {"trace": os.path.basename(f), "segment_rule": "gaps > 5 ms split the post-setup launches; reported segment: " + which, "segments": seg_info,
+       "reported_segment": pick, "setup": summarise(rows[:last_setup + 1]), "solve": summarise(segs[pick] if segs else solve)}
 # the driver's tail (true-residual check, dumps) is a handful of launches and stays inside "solve"
 print(json.dumps(out, indent=1))
