@@ -311,6 +311,20 @@ def kcycle_c5_schur_and_f32():
             out["fp32_over_fp64"] = out["fp32_kcycle"]["value"] / out["fp64"]["value"]
         if al:
             out["device_allocator_inside_solves_s"] = [float(a[0]) for a in al]
+        out["fp64"]["note"] = ("vectors and arithmetic fp64; the Galerkin matrices and right-block-Jacobi hops of the preconditioner levels are STORED as complex<float> "
+                               "(the facade's default for a hierarchy that only preconditions)")
+        # the same fp64 solve with the reference's storage precision on every level, and with complex<half> storage (opt-in)
+        for key, bits in (("fp64_strict_storage", "64"), ("fp64_16bit_storage", "16")):
+            q = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1", QMG_COARSE_BITS=bits),
+                               capture_output=True, text=True, timeout=900)
+            m2 = re.search(r"setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", q.stdout)
+            it2 = re.search(r"Multigrid (converged|failed to converge) in (\d+) iterations", q.stdout)
+            res2 = re.search(r"Check tolerance ([\d.e+-]+)", q.stdout)
+            if m2 and it2 and res2:
+                out[key] = {"value": float(m2.group(3)), "outer_iterations": int(it2.group(2)), "converged": it2.group(1) == "converged",
+                            "true_residual_original_system": float(res2.group(1)), "solve_s": float(m2.group(2)), "QMG_COARSE_BITS": int(bits)}
+        if "fp32_kcycle" in out and "fp64_strict_storage" in out:
+            out["fp32_over_fp64_strict_storage"] = out["fp32_kcycle"]["value"] / out["fp64_strict_storage"]["value"]
         return out
     except Exception as e:
         return {"error": repr(e)}
@@ -574,6 +588,15 @@ def pmc_traffic(L):
     return None, "no PMC passes committed for this configuration"
 
 
+def kcycle_c3_16bit():
+    """`also_kcycle` with QMG_COARSE_BITS=16: the Galerkin matrices of the preconditioner levels stored as complex<half> (opt-in; a quarter of
+    the fp64 matrix stream; vectors, arithmetic and the outer solve fp64)."""
+    out = kcycle_c3(extra_env={"QMG_COARSE_BITS": "16"})
+    if "workload" in out:
+        out["workload"] = out["workload"].replace("complex<float> (the facade's default)", "complex<half> (opt-in, QMG_COARSE_BITS=16)")
+    return out
+
+
 def kcycle_c3_strict_fp64():
     """`also_kcycle` with QMG_COARSE_F32=0: the Galerkin coarse matrices stay complex<double> (the reference's storage precision on
     every level).  Reported beside the default, in which the preconditioner levels STORE their matrices as complex<float>
@@ -604,7 +627,7 @@ def kcycle_c3(extra_env=None):
         res = re.search(r"Check tolerance ([\d.e+-]+)", p.stdout)
         ops = re.findall(r"Level (\d) .* Total (\d+)", p.stdout)
         al = re.search(r"device allocator inside the solve ([\d.e+-]+) s in (\d+) calls", p.stdout)
-        f32c = "complex<float>" in p.stdout
+        f32c = "complex<float>" in p.stdout or "complex<half>" in p.stdout
         return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, fp64, 1 GPU" + ("; Galerkin matrices of the preconditioner levels stored as complex<float> (the facade's default), arithmetic and vectors fp64" if f32c else ""),
                 "metric": "outer VPGCR iterations per second",
                 "value": float(m.group(3)), "outer_iterations": int(it.group(2)), "converged": it.group(1) == "converged",
@@ -911,6 +934,7 @@ def main():
         out["also_kcycle"]["cpu_reference_same_system"] = kcycle_cpu_reference()
         out["also_kcycle_c5_schur"] = kcycle_c5_schur_and_f32()
         out["also_kcycle_strict_fp64"] = kcycle_c3_strict_fp64()
+        out["also_kcycle_16bit_storage"] = kcycle_c3_16bit()
         out["also_kcycle_batched"] = kcycle_c3_batched()
         # the same configuration with the K-cycle in complex<float> (the outer solve, its tolerance and the residual check stay fp64): one system, then 8
         f1, f8 = kcycle_c3_batched(1, f32=True), kcycle_c3_batched(8, f32=True)

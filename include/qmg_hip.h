@@ -142,6 +142,10 @@ int qmg_stencil_apply_batch(const qmg_stencil_desc* d, void* lhs, const void* rh
  * ROUNDED matrices.  nc = 1, 2, 4 return QMG_ERR_UNSUPPORTED.  nrhs <= 16, mask as in qmg_stencil_apply_batch. */
 int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                             int nrhs, size_t vec_stride, unsigned mask, void* stream);
+/* The same with the matrices stored as complex<half> (qmg_convert_to_c16) and vectors of either precision; nc a multiple of 4 and > 4
+ * (QMG_ERR_UNSUPPORTED otherwise).  qmg_stencil_apply_epi_t takes mat32 = 2 for this storage. */
+int qmg_stencil_apply_mat16_t(int vec_dtype, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                              int nrhs, size_t vec_stride, unsigned mask, void* stream);
 int qmg_c64_to_c32(void* dst_f32, const void* src_f64, size_t n, void* stream);
 
 /* ---------------- operator construction from U(1) links (device side) ---------------- */
@@ -329,6 +333,7 @@ int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* 
  * complex<half> copies (qmg_convert_to_c16), vectors are complex<float>, arithmetic fp32: 112 B/site instead of 192.  The
  * rounding (2^-11) perturbs the OPERATOR, so this is for applies inside a preconditioner only. */
 int qmg_convert_to_c16(void* dst_c16, const void* src, int src_dtype, size_t n, void* stream);
+int qmg_convert_from_c16(void* dst, int dst_dtype, const void* src_c16, size_t n, void* stream);   /* complex<half> -> QMG_C64 / QMG_C32, exact */
 int qmg_stencil_apply_h16(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
                           int nrhs, size_t vec_stride, unsigned mask, void* stream);
 

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
     "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
-    "qmg_convert_to_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_norm2",
+    "qmg_convert_to_c16", "qmg_convert_from_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_mat16_t", "qmg_stencil_apply_norm2",
     "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_staggered_fill_slab", "qmg_laplace_fill_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
     "qmg_stencil_apply_epi_t", "qmg_wilson_apply_direct_epi", "qmg_wilson_hops_direct_epi", "qmg_batch_mr_dots_t", "qmg_batch_mr_update_t", "qmg_batch_mr_read_dots",
     "qmg_u1_heatbath_noncompact", "qmg_u1_phase_to_gauge", "qmg_u1_gauge_to_phase", "qmg_u1_plaquette", "qmg_u1_noncompact_action",
@@ -461,6 +461,15 @@ def stencil_apply_batch(desc, lhs, rhs, pieces, nrhs, vec_stride, mask, stream=N
 def stencil_apply_mat32(desc, lhs, rhs, pieces, nrhs, vec_stride, mask, stream=None):
     check(lib().qmg_stencil_apply_mat32(C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream),
           "qmg_stencil_apply_mat32")
+
+
+def stencil_apply_mat16(vec_dtype, desc, lhs, rhs, pieces, nrhs=1, vec_stride=0, mask=1, stream=None):
+    """status of qmg_stencil_apply_mat16_t: complex<half> matrices (convert_to_c16), vectors of vec_dtype"""
+    return lib().qmg_stencil_apply_mat16_t(vec_dtype, C.byref(desc), _vp(lhs), _vp(rhs), C.c_uint(pieces), nrhs, C.c_size_t(vec_stride), C.c_uint(mask), stream)
+
+
+def convert_from_c16(dst, dst_dtype, src, n):
+    check(lib().qmg_convert_from_c16(_vp(dst), dst_dtype, _vp(src), C.c_size_t(n), None), "qmg_convert_from_c16")
 
 
 def c64_to_c32(dst, src, n):

@@ -220,6 +220,14 @@ __global__ __launch_bounds__(BLOCK) void k_to_half(__half2* __restrict__ dst, co
   }
 }
 
+template <typename TD>
+__global__ __launch_bounds__(BLOCK) void k_from_half(void* __restrict__ dst, const __half2* __restrict__ src, long n) {
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float2 f = __half22float2(src[i]);
+    stc<TD>(dst, i, cmake((double)f.x, (double)f.y));
+  }
+}
+
 int g_site_block = BLOCK, g_site_gy = 0;
 int g_site_generic = 0;   // "site_generic": 1 forces the run-time-flag kernel (SHAPE 0)
 
@@ -304,6 +312,16 @@ int qmg_convert_to_c16(void* dst_c16, const void* src, int src_dtype, size_t n, 
   if (n == 0) return QMG_SUCCESS;
   if (src_dtype == QMG_C32) k_to_half<float><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((__half2*)dst_c16, src, (long)n);
   else k_to_half<double><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>((__half2*)dst_c16, src, (long)n);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
+// complex<half> -> complex<double> or complex<float> (dst_dtype), exact
+int qmg_convert_from_c16(void* dst, int dst_dtype, const void* src_c16, size_t n, void* stream) {
+  if (!valid_dtype(dst_dtype) || ((!dst || !src_c16) && n)) return QMG_ERR_INVALID;
+  if (n == 0) return QMG_SUCCESS;
+  if (dst_dtype == QMG_C32) k_from_half<float><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>(dst, (const __half2*)src_c16, (long)n);
+  else k_from_half<double><<<grid_1d(n), BLOCK, 0, as_stream(stream)>>>(dst, (const __half2*)src_c16, (long)n);
   QMG_LAUNCH_CHECK();
   return QMG_SUCCESS;
 }

@@ -49,6 +49,7 @@ struct StencilArgs {
   unsigned char ridx[16];   // masked batches (qmg_stencil_apply_batch): right-hand side processed as column k; else unused
   int use_idx;       // 0: column k is right-hand side k
   int mat32;         // 1: clover / hopping point to complex<float> arrays (kernels B and C: qmg_stencil_apply_mat32, qmg_stencil_apply_t)
+  int mat16;         // 1 (with mat32 = 1): they point to complex<half> arrays; the tile is widened to complex<float> on its way into LDS (kernel B32: qmg_stencil_apply_mat16)
   int vec32;         // 1: lhs / rhs are complex<float> (qmg_stencil_apply_t with QMG_C32: matrices AND vectors fp32)
   // y-slab of a larger lattice (kernel B only; qmg_stencil_apply_slab): rows -1 / Ly of the right-hand side come from these
   // buffers ([system][parity][hr][nc] complex, halo_stride elements between systems) instead of the periodic wrap
@@ -729,7 +730,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 // loads carry two matrix elements, the staging registers and the LDS tile hold raw float pairs (half the registers, half
 // the LDS: twice the resident blocks), and an element is widened to fp64 only when it is multiplied.  PP = staged PAIRS per
 // thread.  Row stride nc + 2 floats-pairs: even (16-B aligned pair stores) and conflict-free for the 8-byte row reads.
-template <int PP, int KR, bool V32, bool EPI = false>
+// M16: the matrices are stored as complex<half> (qmg_stencil_apply_mat16; nc a multiple of 4): a 16-B load carries FOUR elements (PP = staged quads
+// per thread), which are widened to complex<float> when they are parked -- the LDS tile and everything behind it are those of the fp32 form.
+template <int PP, int KR, bool V32, bool EPI = false, bool M16 = false>
 __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, const int nc, const GenLayout L) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int rs32 = nc + 2;
@@ -795,11 +798,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
         long moff = (piece == 4) ? site0 * nc2 : (long)piece * a.size_cm + site0 * nc2;   //  code serves both matrix widths)
         const int lim = nsite * (int)nc2;
         const float2* m32 = reinterpret_cast<const float2*>(mbase) + moff;
+        const unsigned* m16 = reinterpret_cast<const unsigned*>(mbase) + moff;   // complex<half>: 4 B per element
 #pragma unroll
         for (int q = 0; q < PP; q++) {
-          const int el = 2 * (tid + q * BLOCK);
+          const int el = (M16 ? 4 : 2) * (tid + q * BLOCK);
           if (el < lim) {
-            const double* pp = reinterpret_cast<const double*>(m32 + el);
+            const double* pp = M16 ? reinterpret_cast<const double*>(m16 + el) : reinterpret_cast<const double*>(m32 + el);
             stage[q].x = __builtin_nontemporal_load(pp);
             stage[q].y = __builtin_nontemporal_load(pp + 1);
           } else stage[q] = make_double2(0.0, 0.0);
@@ -826,10 +830,18 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
         // registers -> LDS (padded rows)
 #pragma unroll
         for (int q = 0; q < PP; q++) {
-          const int el = 2 * (tid + q * BLOCK);
-          if (el < L.mat_elems) {   // (nc even: the pair never straddles a row; rs32 and cc even: 16-B aligned)
+          const int el = (M16 ? 4 : 2) * (tid + q * BLOCK);
+          if (el < L.mat_elems) {   // (nc even: the pair never straddles a row; rs32 and cc even: 16-B aligned.  M16: nc % 4 == 0, the quad stays in its row)
             const int rowi = el / nc, cc = el - rowi * nc;
-            *reinterpret_cast<double2*>(mlds + (size_t)rowi * rs32 + cc) = stage[q];
+            if constexpr (M16) {
+              typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+              typedef float f4 __attribute__((ext_vector_type(4)));
+              const h8 hv = __builtin_bit_cast(h8, stage[q]);   // (re, im) x 4
+              const f4 w0 = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}, w1 = {(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+              *reinterpret_cast<f4*>(mlds + (size_t)rowi * rs32 + cc) = w0;
+              *reinterpret_cast<f4*>(mlds + (size_t)rowi * rs32 + cc + 2) = w1;
+            } else
+              *reinterpret_cast<double2*>(mlds + (size_t)rowi * rs32 + cc) = stage[q];
           }
         }
         if (tid < L.S * nc) {
@@ -926,9 +938,12 @@ __device__ __forceinline__ void wave_lds_handoff() {
 //         (re or im of M[r][c], sign by quadrant) straight out of the complex LDS tile.  The MFMA count is 2 nc/16 (rounded up) x nc/2
 //         per piece instead of MODE 0's 4 x ceil(nc/16) x ceil(nc/4): nc = 24: 36 instead of 48 (48 real rows fill three tiles exactly,
 //         24 complex rows waste a quarter of two), nc = 8: 4 instead of 8.  At 16 systems the kernel is MFMA-bound, so that is its time.
-template <int NC, int MODE, bool M32, bool V32, bool VL>
+// M16 (with M32): the matrices are stored as complex<half> (NC % 4 == 0): a lane's 16-B load carries four elements, widened to the complex<float>
+// tile when they are parked; everything behind the tile is the M32 form.
+template <int NC, int MODE, bool M32, bool V32, bool VL, bool M16 = false>
 __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
   static_assert(MODE != 2 || (VL && !M32 && NC % 2 == 0), "MODE 2: fp64, right-hand sides through the LDS slice");
+  static_assert(!M16 || (M32 && NC % 4 == 0), "16-bit matrices: the fp32 tile path, quads that stay inside a row");
   constexpr int RT = (MODE == 2) ? (2 * NC + 15) / 16 : (NC + 15) / 16, KS = (MODE == 2) ? NC / 2 : (NC + 3) / 4;
   constexpr int NACC = (MODE == 2) ? 1 : 2;
   // LDS row stride in tile elements: fp64 tile nc+1 complex (odd: conflict-free 16-B reads); fp32-stored matrices keep the
@@ -980,7 +995,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
         else acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
       }
 
-    constexpr int NGP = (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS per lane per piece (fp32-stored matrices)
+    constexpr int NGP = M16 ? (NC2 / 4 + WAVE - 1) / WAVE : (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS (16-bit: QUADS) per lane per piece (narrow-stored matrices)
     // staging registers for the matrix stream (a second set, two pieces of prefetch, was measured SLOWER: 8 rhs 2.88 -> 3.10
     // ms; the registers cost a resident wavefront and the stream was not the limit -- profiles/r02_mfma_kernelC_variants.txt)
     constexpr int NGS = M32 ? NGP : NG;
@@ -1024,12 +1039,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
     auto load_matrix = [&](int pc, int gs) {      // global -> registers, lane-linear, non-temporal
       const cplx* mbase = (pc == 0) ? a.clover : a.hopping;
       const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * NC2;
-      if (M32) {   // pairs of complex<float>: 16 B per lane per load, kept as raw bits
+      if (M32) {   // pairs of complex<float> (M16: quads of complex<half>): 16 B per lane per load, kept as raw bits
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
-          const int el = 2 * (g * WAVE + lane);
-          if (NC2 % (2 * WAVE) == 0 || el < NC2) {
-            const double* pp = reinterpret_cast<const double*>(reinterpret_cast<const float2*>(mbase) + moff + el);
+          constexpr int PER = M16 ? 4 : 2;
+          const int el = PER * (g * WAVE + lane);
+          if (NC2 % (PER * WAVE) == 0 || el < NC2) {
+            const double* pp = M16 ? reinterpret_cast<const double*>(reinterpret_cast<const unsigned*>(mbase) + moff + el)
+                                   : reinterpret_cast<const double*>(reinterpret_cast<const float2*>(mbase) + moff + el);
             G[gs][g].x = __builtin_nontemporal_load(pp);
             G[gs][g].y = __builtin_nontemporal_load(pp + 1);
           } else G[gs][g] = cmake(0.0, 0.0);
@@ -1072,8 +1089,20 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
       if (M32) {
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
-          const int el = 2 * (g * WAVE + lane);
-          if (NC2 % (2 * WAVE) == 0 || el < NC2) *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[gs][g];   // 16-B aligned: RS, el even
+          constexpr int PER = M16 ? 4 : 2;
+          const int el = PER * (g * WAVE + lane);
+          if (NC2 % (PER * WAVE) == 0 || el < NC2) {
+            if constexpr (M16) {   // (re, im) x 4 halves -> two 16-B stores of complex<float> pairs (RS even, el % 4 == 0: aligned, same row)
+              typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+              typedef float f4 __attribute__((ext_vector_type(4)));
+              const h8 hv = __builtin_bit_cast(h8, G[gs][g]);
+              const f4 w0 = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}, w1 = {(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+              float2* dst = mlds32 + (el / NC) * RS + (el % NC);
+              *reinterpret_cast<f4*>(dst) = w0;
+              *reinterpret_cast<f4*>(dst + 2) = w1;
+            } else
+              *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[gs][g];   // 16-B aligned: RS, el even
+          }
         }
       } else {
 #pragma unroll
@@ -1359,7 +1388,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
                               double* norms_dev = nullptr, const qmg_apply_epilogue* epi = nullptr);
 
 // One system with an epilogue on the finished site values (include/qmg_hip.h: qmg_apply_epilogue).  dtype QMG_C64: fp64 matrices and
-// vectors; mat32 != 0: complex<float> matrices (d->clover / d->hopping point to float pairs) with fp64 vectors; QMG_C32: both fp32.
+// vectors; mat32 == 1: complex<float> matrices (d->clover / d->hopping point to float pairs), mat32 == 2: complex<half> matrices, with fp64 vectors;
+// QMG_C32: fp32 vectors with either.
 // QMG_ERR_UNSUPPORTED where the dispatch lands on a kernel without the epilogue (nc = 1, 2, 4; batches): the caller runs the
 // separate passes instead.
 extern "C" int qmg_stencil_apply_epi_t(int dtype, int mat32, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, size_t vec_stride, int system,
@@ -1369,7 +1399,7 @@ extern "C" int qmg_stencil_apply_epi_t(int dtype, int mat32, const qmg_stencil_d
   if (mat32 && d && (d->nc == 1 || d->nc == 2 || d->nc == 4)) return QMG_ERR_UNSUPPORTED;
   unsigned char ridx[16];
   for (int k = 0; k < 16; k++) ridx[k] = (unsigned char)system;
-  return stencil_apply_impl(d, lhs, rhs, pieces, 1, vec_stride, system ? ridx : nullptr, stream, mat32 ? 1 : 0, dtype == QMG_C32 ? 1 : 0, nullptr, nullptr, epi);
+  return stencil_apply_impl(d, lhs, rhs, pieces, 1, vec_stride, system ? ridx : nullptr, stream, mat32 == 2 ? 2 : mat32 ? 1 : 0, dtype == QMG_C32 ? 1 : 0, nullptr, nullptr, epi);
 }
 
 // partials of the fused norms (one buffer per host thread = per rank, grown on demand) and the default result slot
@@ -1420,6 +1450,23 @@ extern "C" int qmg_stencil_apply_mat32(const qmg_stencil_desc* d, void* lhs, con
   if (n == 0) return QMG_SUCCESS;
   if (n == nrhs) return stencil_apply_impl(d, lhs, rhs, pieces, nrhs, vec_stride, nullptr, stream, 1);
   return stencil_apply_impl(d, lhs, rhs, pieces, n, vec_stride, ridx, stream, 1);
+}
+
+// Matrices stored as complex<half> (d->clover / d->hopping point to __half2 pairs: qmg_convert_to_c16), vectors complex<double> (QMG_C64) or
+// complex<float> (QMG_C32), accumulation fp64.  A quarter of the fp64 matrix stream.  For operators that only PRECONDITION; nc a multiple of 4
+// (the Galerkin operators: 8, 12, 16, 24, 32); QMG_ERR_UNSUPPORTED otherwise.  The values must be inside half range (|x| < 65504; magnitudes
+// below 6e-8 flush to zero): the caller checks that when it converts.
+extern "C" int qmg_stencil_apply_mat16_t(int vec_dtype, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces,
+                                         int nrhs, size_t vec_stride, unsigned mask, void* stream) {
+  if (vec_dtype != QMG_C64 && vec_dtype != QMG_C32) return QMG_ERR_INVALID;
+  if (!d || (d->nc & 3) || d->nc == 4) return QMG_ERR_UNSUPPORTED;
+  if (nrhs < 1 || nrhs > 16) return QMG_ERR_INVALID;
+  unsigned char ridx[16];
+  int n = 0;
+  for (int k = 0; k < nrhs; k++)
+    if ((mask >> k) & 1u) ridx[n++] = (unsigned char)k;
+  if (n == 0) return QMG_SUCCESS;
+  return stencil_apply_impl(d, lhs, rhs, pieces, n == nrhs ? nrhs : n, vec_stride, n == nrhs ? nullptr : ridx, stream, 2, vec_dtype == QMG_C32 ? 1 : 0);
 }
 
 // lhs_k (+)= pieces(M) rhs_k and norms[k] = |lhs_k|^2 from the same pass (the vector is not read again): fp64, nc = 1 or 2,
@@ -1556,7 +1603,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.nrhs = nrhs;
   a.vec_stride = (long)vec_stride;
   a.use_idx = ridx ? 1 : 0;
-  a.mat32 = mat32;
+  a.mat32 = mat32 ? 1 : 0;
+  a.mat16 = (mat32 == 2) ? 1 : 0;   // (mat32 == 2: complex<half> storage)
   a.halo_lo = slab ? slab->lo : nullptr;
   a.halo_hi = slab ? slab->hi : nullptr;
   a.halo_stride = slab ? slab->stride : 0;
@@ -1705,7 +1753,8 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       int mode = (g_stencil_mfma == 2 || nk > 8) ? 0 : 1;
       // 9-16 systems in fp64: the real-form tiles where they save MFMAs (nc = 24: 36 instead of 48 per piece; nc = 8: 4 instead of 8)
       if (mode == 0 && g_stencil_mfma == 1 && g_mfma_vl && !a.mat32 && !a.vec32 && (nc == 24 || nc == 8)) mode = 2;
-      if (g_mfma_vl && !(mode == 0 && a.mat32)) smem += sizeof(cplx) * (size_t)(BLOCK / WAVE) * (mode == 1 ? 8 : 16) * (nc + 1);   // the wavefronts' vector slices
+      const bool vl_slices = a.mat16 ? (mode == 1) : (g_mfma_vl && !(mode == 0 && a.mat32));   // (the 16-bit instantiations: VL with MODE 1, not with MODE 0)
+      if (vl_slices) smem += sizeof(cplx) * (size_t)(BLOCK / WAVE) * (mode == 1 ? 8 : 16) * (nc + 1);   // the wavefronts' vector slices
 #define QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, VL)                                                              \
       {                                                                                                         \
         if (smem > 64 * 1024)                                                                                   \
@@ -1713,8 +1762,15 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
         k_stencil_mfma<NC, MODE, M32, V32, VL><<<grid, block, smem, st>>>(b, nk);                             \
       }
 #define QMG_MFMA_LAUNCH1(NC, MODE, M32, V32) { if (g_mfma_vl && !(MODE == 0 && M32)) QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, true) else QMG_MFMA_LAUNCH0(NC, MODE, M32, V32, false) }
+#define QMG_MFMA_LAUNCH16(NC, MODE, V32)                                                                        \
+      {                                                                                                         \
+        if (smem > 64 * 1024)                                                                                   \
+          QMG_HIP_CHECK(hipFuncSetAttribute((const void*)k_stencil_mfma<NC, MODE, true, V32, MODE == 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        k_stencil_mfma<NC, MODE, true, V32, MODE == 1, true><<<grid, block, smem, st>>>(b, nk);               \
+      }
 #define QMG_MFMA_LAUNCH2(NC, MODE)                                                                              \
-      { if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
+      { if (a.mat16) { if (a.vec32) QMG_MFMA_LAUNCH16(NC, MODE, true) else QMG_MFMA_LAUNCH16(NC, MODE, false) }  \
+        else if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
       if (mode == 2) QMG_MFMA_LAUNCH0(NC, 2, false, false, true) else if (mode == 0) QMG_MFMA_LAUNCH2(NC, 0) else QMG_MFMA_LAUNCH2(NC, 1)
       switch (nc) {
@@ -1728,6 +1784,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #undef QMG_MFMA_LAUNCH1
 #undef QMG_MFMA_LAUNCH0
 #undef QMG_MFMA_LAUNCH2
+#undef QMG_MFMA_LAUNCH16
     }
     QMG_LAUNCH_CHECK();
     return QMG_SUCCESS;
@@ -1737,8 +1794,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   if (a.mat32 && !(nc & 1) && g_gen32 && !slab) {   // (kernel B32 has no halo step: a slab's fp32 applies go through kernel B's widening loads)
     // kernel B32: fp32 tile end to end (even nc)
     const GenLayout L = make_gen_layout(nc, a.hr, g_gen32 == 2 ? 1 : 0);
-    const int pp = (L.mat_elems / 2 + BLOCK - 1) / BLOCK;
-    if (pp >= 1 && pp <= 6) {
+    if (a.mat16 && (nc & 3)) return QMG_ERR_UNSUPPORTED;
+    const int pp = a.mat16 ? (L.mat_elems / 4 + BLOCK - 1) / BLOCK : (L.mat_elems / 2 + BLOCK - 1) / BLOCK;
+    if (pp >= 1 && pp <= (a.mat16 ? 3 : 6)) {
       int kr = (a.nrhs >= 5) ? 8 : (a.nrhs >= 2) ? 4 : 1;
       auto smem_of = [&](int k) { return (((size_t)L.S * nc * (nc + 2) * 8 + 15) & ~(size_t)15) + sizeof(cplx) * ((size_t)k * L.S * nc + (size_t)L.H * L.S * nc); };
       while (kr > 1 && smem_of(kr) > 48 * 1024) kr = (kr == 8) ? 4 : 1;
@@ -1750,7 +1808,15 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
 #define QMG_G32_CASE2(PP, KR) { if (a.vec32) k_stencil_gen32<PP, KR, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, KR, false><<<grid, block, smem, st>>>(a, nc, L); }
 #define QMG_G32_EPI(PP) { if (a.vec32) k_stencil_gen32<PP, 1, true, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, 1, false, true><<<grid, block, smem, st>>>(a, nc, L); }
 #define QMG_G32_CASE(PP) case PP: { if (kr == 8) { QMG_G32_CASE2(PP, 8) } else if (kr == 4) { QMG_G32_CASE2(PP, 4) } else if (a.epi.on) { QMG_G32_EPI(PP) } else { QMG_G32_CASE2(PP, 1) } } break;
+#define QMG_G16_CASE2(PP, KR) { if (a.vec32) k_stencil_gen32<PP, KR, true, false, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, KR, false, false, true><<<grid, block, smem, st>>>(a, nc, L); }
+#define QMG_G16_EPI(PP) { if (a.vec32) k_stencil_gen32<PP, 1, true, true, true><<<grid, block, smem, st>>>(a, nc, L); else k_stencil_gen32<PP, 1, false, true, true><<<grid, block, smem, st>>>(a, nc, L); }
+#define QMG_G16_CASE(PP) case PP: { if (kr == 8) { QMG_G16_CASE2(PP, 8) } else if (kr == 4) { QMG_G16_CASE2(PP, 4) } else if (a.epi.on) { QMG_G16_EPI(PP) } else { QMG_G16_CASE2(PP, 1) } } break;
+        if (a.mat16) { switch (pp) { QMG_G16_CASE(1) QMG_G16_CASE(2) QMG_G16_CASE(3) default: break; } }
+        else
         switch (pp) { QMG_G32_CASE(1) QMG_G32_CASE(2) QMG_G32_CASE(3) QMG_G32_CASE(4) QMG_G32_CASE(5) QMG_G32_CASE(6) default: break; }
+#undef QMG_G16_CASE
+#undef QMG_G16_EPI
+#undef QMG_G16_CASE2
 #undef QMG_G32_CASE
 #undef QMG_G32_EPI
 #undef QMG_G32_CASE2
@@ -1760,6 +1826,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       }
     }
   }
+  if (a.mat16) return QMG_ERR_UNSUPPORTED;   // complex<half> matrices are served by kernel B32 only (nc a multiple of 4, no slabs)
   GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
   // right-hand sides per pass of kernel B: 4 (2-4 systems) or 8 accumulators; if the tile plus the vectors of the pass do

@@ -108,7 +108,7 @@ inline int N13::build(int argc, char** argv) {
   const bool root = !dd || qmg::slab().rank == 0;
   if (!dd && !qmg::ok(qmg_init(getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0), "qmg_init")) return 2;
   // Galerkin matrices of the preconditioner levels are STORED as complex<float> by default (multigrid.hpp); QMG_COARSE_F32=0 keeps them fp64
-  if (getenv("QMG_COARSE_F32")) MultigridMG::coarse_f32_storage() = atoi(getenv("QMG_COARSE_F32")) != 0 ? 1 : 0;
+  MultigridMG::coarse_storage_from_env();   // QMG_COARSE_F32=0/1, QMG_COARSE_BITS=64/32/16
   x_len = stoi(argv[1]); y_len = stoi(argv[1]);
   mass = stod(argv[2]);
   const double beta = stod(argv[3]);
@@ -250,7 +250,8 @@ inline int N13::build(int argc, char** argv) {
   }
   qmg_stream_sync(0);
   if (root && cgne) cout << "[QMG-INFO]: CGNE smoothers (MR on M M^dagger, then M^dagger) on every level\n";
-  if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
+  if (root && mg_object->any_coarse_f16()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<half> (QMG_COARSE_BITS=16; default 32, 64: fp64)\n";
+  else if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
   if (root) cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
        << " s ; total " << setup_s << " s\n" << setprecision(20);

@@ -28,6 +28,7 @@ using namespace std;
 
 static int run(int rank, int world, int device, bool slab_mode, int argc, char** argv) {
   if (!qmg::ok(qmg_init(device), "qmg_init")) return 2;
+  MultigridMG::coarse_storage_from_env();   // QMG_COARSE_F32=0/1, QMG_COARSE_BITS=64/32/16 (default: complex<float> copies on the preconditioner levels)
   if (slab_mode) {
     if (!qmg::ok(qmg_comm_init_env(world, rank), "qmg_comm_init_env") || !qmg::slab_begin()) return 2;
   }

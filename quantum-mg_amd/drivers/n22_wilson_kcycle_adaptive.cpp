@@ -119,7 +119,7 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
     cout << "[QMG-INFO]: rank " << rank << " of " << world << " on device " << local_rank << "\n";
   }
   // Galerkin matrices of the preconditioner levels are STORED as complex<float> by default (multigrid.hpp); QMG_COARSE_F32=0 keeps them fp64
-  if (getenv("QMG_COARSE_F32")) MultigridMG::coarse_f32_storage() = atoi(getenv("QMG_COARSE_F32")) != 0 ? 1 : 0;
+  MultigridMG::coarse_storage_from_env();   // QMG_COARSE_F32=0/1, QMG_COARSE_BITS=64/32/16
   const int x_len = stoi(argv[1]), y_len = x_len;
   const double mass = stod(argv[2]);
   const int n_refine = stoi(argv[4]);
@@ -329,6 +329,8 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
   }
   qmg_stream_sync(qmg::current_stream());
   const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
+  if (mg_object->any_coarse_f16()) cout << "[QMG-INFO]: Galerkin matrices (and right-block-Jacobi hops) of the preconditioner levels are stored as complex<half> (QMG_COARSE_BITS=16; default 32, 64: fp64)\n";
+  else if (mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices (and right-block-Jacobi hops) of the preconditioner levels are stored as complex<float> (QMG_COARSE_BITS=64: fp64)\n";
 
   const long n0 = lats[0]->get_size_cv_l();
   complex<double>* b = mg_object->check_out(0);

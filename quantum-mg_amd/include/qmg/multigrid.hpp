@@ -103,7 +103,9 @@ class MultigridMG {
   //   -1 (default): ON for a StatefulMultigridMG -- a hierarchy that only PRECONDITIONS a flexible fp64 outer solve, whose true
   //      residual still reaches its fp64 tolerance (C3: the same 13 outer iterations, 1e-10) -- and OFF for a plain MultigridMG,
   //      whose coarse operators are used as operators (Galerkin identity R A P to 1e-15: n08);
-  //    0 / 1: off / on for both (drivers: QMG_COARSE_F32=0 / 1).
+  //    0 / 1: off / on for both (drivers: QMG_COARSE_F32=0 / 1);
+  //    2: ON with complex<half> copies (Stencil2D::enable_f32_matrices(16): a quarter of the fp64 stream; levels whose nc or value range
+  //       does not allow it keep complex<float>) -- opt-in (drivers: QMG_COARSE_BITS=16).
   static int& coarse_f32_storage() { static int f = -1; return f; }
   virtual bool coarse_f32_default() const { return false; }
   // (y-slab mode keeps fp64 coarse matrices: the slab kernels stream the fp64 arrays; nc = 1, 2, 4 have no fp32-stored kernel)
@@ -114,6 +116,12 @@ class MultigridMG {
   }
   // true if any level of this hierarchy streams complex<float> Galerkin matrices (drivers print it)
   bool any_coarse_f32() { for (int i = 1; i < num_levels; i++) if (stencil_list[i] && stencil_list[i]->f32_matrices) return true; return false; }
+  bool any_coarse_f16() { for (int i = 1; i < num_levels; i++) if (stencil_list[i] && stencil_list[i]->f32_matrices && stencil_list[i]->f32_bits == 16) return true; return false; }
+  // drivers: QMG_COARSE_F32=0 / 1 and QMG_COARSE_BITS=64 / 32 / 16 (the latter wins)
+  static void coarse_storage_from_env() {
+    if (getenv("QMG_COARSE_F32")) coarse_f32_storage() = atoi(getenv("QMG_COARSE_F32")) != 0 ? 1 : 0;
+    if (getenv("QMG_COARSE_BITS")) { const int b = atoi(getenv("QMG_COARSE_BITS")); coarse_f32_storage() = (b == 16) ? 2 : (b == 32) ? 1 : 0; }
+  }
 
   enum QMGMultigridPrecondStencil { QMG_MULTIGRID_PRECOND_ORIGINAL = 0, QMG_MULTIGRID_PRECOND_RIGHT_BLOCK_JACOBI = 1 };
 
@@ -149,7 +157,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list.push_back(new CoarseOperator2D(new_lat, stencil_list[num_levels - 2], lattice_list[num_levels - 2], new_transfer, is_chiral,
                                                   build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra));
-      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list.back()->enable_f32_matrices();
+      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list.back()->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32);
       is_stencil_managed.push_back(true);
     } else {
       stencil_list.push_back(0);
@@ -195,7 +203,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list[level] = new CoarseOperator2D(new_lat, stencil_list[level - 1], lattice_list[level - 1], new_transfer, is_chiral,
                                                  build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra);
-      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list[level]->enable_f32_matrices();
+      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list[level]->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32);
       is_stencil_managed[level] = true;
     } else {
       stencil_list[level] = 0;

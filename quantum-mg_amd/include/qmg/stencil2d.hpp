@@ -83,9 +83,11 @@ struct Stencil2D {
       if (rc == QMG_SUCCESS) return;
       if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_apply_direct"); return; }
     }
-    if (f32_in_use() && cl == clover && ho == hopping) {   // opt-in fp32 storage of the ORIGINAL stencil (enable_f32_matrices)
-      d.clover = clover32; d.hopping = hopping32;
-      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat32");
+    const void *ncl = 0, *nho = 0;
+    if (narrow_arrays_for(cl, ho, &ncl, &nho)) {   // fp32 / 16-bit storage of the ORIGINAL stencil or of the right-block-Jacobi hops / cinv (enable_f32_matrices)
+      d.clover = ncl; d.hopping = nho;
+      if (f32_bits == 16) qmg::ok(qmg_stencil_apply_mat16_t(QMG_C64, &d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat16_t");
+      else qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, 1, 0, 1u, qmg::current_stream()), "qmg_stencil_apply_mat32");
       return;
     }
     qmg::ok(qmg_stencil_apply(&d, lhs, rhs, pieces, 1, 0, qmg::current_stream()), "qmg_stencil_apply");
@@ -102,10 +104,13 @@ struct Stencil2D {
   complex<double> shift, eo_shift, dof_shift;
   // opt-in: complex<float> copies of clover / hopping that the ORIGINAL-operator applies stream instead of the fp64 arrays
   bool f32_matrices;
+  int f32_bits;   // 32: clover32 / hopping32 hold complex<float>; 16: complex<half> (enable_f32_matrices(16))
   // the fp32 copies mirror the ORIGINAL arrays: while a variant (dagger, rbjacobi, rbj-dagger) is swapped into clover / hopping they do not apply
   bool f32_in_use() const { return f32_matrices && !swap_dagger && !swap_rbjacobi && !swap_rbj_dagger; }
   void* clover32;
   void* hopping32;
+  void* rbj_hopping32;   // the same narrow storage for the right-block-Jacobi hops and cinv (the Schur K-cycle's matrix stream), when that stencil is built
+  void* rbj_cinv32;
 
   // fp32 shadow (qmg_dtype QMG_C32; not in the reference, which is fp64 only): complex<float> copies of the arrays a
   // K-cycle level streams -- the ORIGINAL clover / hopping and, when built, the right-block-Jacobi hopping and cinv.
@@ -249,7 +254,7 @@ struct Stencil2D {
     priv_cvector = 0;
     extra_cvector = allocate_vector<complex<double>>(lat->get_size_cv_l());
     eo_cvector = 0;
-    f32_matrices = false; clover32 = hopping32 = 0;
+    f32_matrices = false; f32_bits = 32; clover32 = hopping32 = 0; rbj_hopping32 = rbj_cinv32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
     f32.dagger_clover = f32.dagger_hopping = 0;
     direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false; direct.rbj_scale = 0.0;
@@ -321,24 +326,71 @@ struct Stencil2D {
   // an HBM-bound coarse apply.  Vectors, shifts and arithmetic stay fp64; the fp64 arrays remain the master copy (variant
   // builds read them; a Galerkin build of the next level probes through the applies and so sees the rounded operator).
   // Call again after changing the matrices.  Not available for nc = 1, 2, 4 (the fine operators).
-  bool enable_f32_matrices() {
+  // bits = 16: the copy is complex<half> (a quarter of the fp64 stream; qmg_stencil_apply_mat16_t: nc a multiple of 4 and > 4) when every
+  // entry is inside half range (|x| < 6e4; magnitudes below 6e-8 flush to zero) -- otherwise the complex<float> copy is kept, with a line
+  // saying so.  Measured on the n13 / n22 hierarchies: the same outer iteration counts as with fp32 storage.
+  bool enable_f32_matrices(int bits = 32) {
     const int nc = lat->get_nc();
     if (nc == 1 || nc == 2 || nc == 4) { std::cout << "[QMG-WARNING]: fp32 matrix storage is not available for nc = " << nc << ".\n"; return false; }
     disable_f32_matrices();
+    if (bits == 16) {
+      const double big = std::max(clover ? norminf(clover, (size_t)lat->get_size_cm_l()) : 0.0, hopping ? norminf(hopping, (size_t)lat->get_size_hopping_l()) : 0.0);
+      if ((nc & 3) || !(big < 6.0e4)) {
+        std::cout << "[QMG-INFO]: 16-bit matrix storage not used on this level (nc = " << nc << ", largest entry " << big << "): complex<float> instead.\n";
+        bits = 32;
+      }
+    }
+    const size_t esz = (bits == 16) ? 4 : 8;
+    auto narrow = [&](void* dst, const complex<double>* src, size_t n) {
+      if (bits == 16) return qmg::ok(qmg_convert_to_c16(dst, src, QMG_C64, n, qmg::current_stream()), "qmg_convert_to_c16");
+      return qmg::ok(qmg_c64_to_c32(dst, src, n, qmg::current_stream()), "qmg_c64_to_c32");
+    };
     if (clover != 0) {
-      if (qmg_malloc(&clover32, (size_t)lat->get_size_cm_l() * 8) != QMG_SUCCESS) { clover32 = 0; return false; }
-      qmg::ok(qmg_c64_to_c32(clover32, clover, (size_t)lat->get_size_cm_l(), qmg::current_stream()), "qmg_c64_to_c32");
+      if (qmg_malloc(&clover32, (size_t)lat->get_size_cm_l() * esz) != QMG_SUCCESS) { clover32 = 0; return false; }
+      narrow(clover32, clover, (size_t)lat->get_size_cm_l());
     }
     if (hopping != 0) {
-      if (qmg_malloc(&hopping32, (size_t)lat->get_size_hopping_l() * 8) != QMG_SUCCESS) { disable_f32_matrices(); return false; }
-      qmg::ok(qmg_c64_to_c32(hopping32, hopping, (size_t)lat->get_size_hopping_l(), qmg::current_stream()), "qmg_c64_to_c32");
+      if (qmg_malloc(&hopping32, (size_t)lat->get_size_hopping_l() * esz) != QMG_SUCCESS) { disable_f32_matrices(); return false; }
+      narrow(hopping32, hopping, (size_t)lat->get_size_hopping_l());
     }
     f32_matrices = true;
+    f32_bits = bits;
+    narrow_rbjacobi_copies();
     return true;
+  }
+  // narrow copies of the right-block-Jacobi hops and cinv (called by enable_f32_matrices and at the end of build_rbjacobi_stencil, whichever
+  // comes second); best effort: without them those applies stream the fp64 arrays
+  void narrow_rbjacobi_copies() {
+    if (rbj_hopping32) { qmg_free(rbj_hopping32); rbj_hopping32 = 0; }
+    if (rbj_cinv32) { qmg_free(rbj_cinv32); rbj_cinv32 = 0; }
+    if (!f32_matrices || !built_rbjacobi || swap_rbjacobi || swap_dagger || swap_rbj_dagger || qmg::slab().on) return;
+    int bits = f32_bits;
+    if (bits == 16) {
+      const double big = std::max(rbjacobi_hopping ? norminf(rbjacobi_hopping, (size_t)lat->get_size_hopping_l()) : 0.0, norminf(rbjacobi_cinv, (size_t)lat->get_size_cm_l()));
+      if (!(big < 6.0e4)) return;   // (one width for all copies of the level: keep fp64 for these)
+    }
+    const size_t esz = (bits == 16) ? 4 : 8;
+    auto narrow = [&](void** dst, const complex<double>* src, size_t n) {
+      if (qmg_malloc(dst, n * esz) != QMG_SUCCESS) { *dst = 0; return; }
+      if (bits == 16) qmg::ok(qmg_convert_to_c16(*dst, src, QMG_C64, n, qmg::current_stream()), "qmg_convert_to_c16");
+      else qmg::ok(qmg_c64_to_c32(*dst, src, n, qmg::current_stream()), "qmg_c64_to_c32");
+    };
+    if (rbjacobi_hopping) narrow(&rbj_hopping32, rbjacobi_hopping, (size_t)lat->get_size_hopping_l());
+    narrow(&rbj_cinv32, rbjacobi_cinv, (size_t)lat->get_size_cm_l());
+  }
+  // the narrow copy that serves (cl, ho) of a launch, if any: ORIGINAL, right-block-Jacobi hops, cinv
+  bool narrow_arrays_for(const void* cl, const void* ho, const void** ncl, const void** nho) const {
+    if (!f32_in_use()) return false;
+    if (cl == clover && ho == hopping && (clover32 || hopping32)) { *ncl = clover32; *nho = hopping32; return true; }
+    if (cl == 0 && ho != 0 && ho == rbjacobi_hopping && rbj_hopping32) { *ncl = 0; *nho = rbj_hopping32; return true; }
+    if (ho == 0 && cl != 0 && cl == rbjacobi_cinv && rbj_cinv32) { *ncl = rbj_cinv32; *nho = 0; return true; }
+    return false;
   }
   void disable_f32_matrices() {
     if (clover32) { qmg_free(clover32); clover32 = 0; }
     if (hopping32) { qmg_free(hopping32); hopping32 = 0; }
+    if (rbj_hopping32) { qmg_free(rbj_hopping32); rbj_hopping32 = 0; }
+    if (rbj_cinv32) { qmg_free(rbj_cinv32); rbj_cinv32 = 0; }
     f32_matrices = false;
   }
 
@@ -547,9 +599,11 @@ struct Stencil2D {
     }
     d.clover = clover_of(set);
     d.hopping = hopping_of(set);
-    if (set == QMG_ARR_ORIGINAL && f32_in_use()) {   // opt-in fp32 STORAGE of the coarse matrices, fp64 vectors (enable_f32_matrices)
-      d.clover = clover32; d.hopping = hopping32;
-      qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
+    const void *ncl = 0, *nho = 0;
+    if (set != QMG_ARR_DAGGER && narrow_arrays_for(d.clover, d.hopping, &ncl, &nho)) {   // fp32 / 16-bit STORAGE of the coarse matrices, fp64 vectors (enable_f32_matrices)
+      d.clover = ncl; d.hopping = nho;
+      if (f32_bits == 16) qmg::ok(qmg_stencil_apply_mat16_t(QMG_C64, &d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat16_t");
+      else qmg::ok(qmg_stencil_apply_mat32(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat32");
       return;
     }
     qmg::ok(qmg_stencil_apply_batch(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_batch");
@@ -594,7 +648,8 @@ struct Stencil2D {
     } else {
       d.clover = clover_of(set);
       d.hopping = hopping_of(set);
-      if (set == QMG_ARR_ORIGINAL && f32_in_use()) { d.clover = clover32; d.hopping = hopping32; mat32 = 1; }
+      const void *ncl = 0, *nho = 0;
+      if (set != QMG_ARR_DAGGER && narrow_arrays_for(d.clover, d.hopping, &ncl, &nho)) { d.clover = ncl; d.hopping = nho; mat32 = (f32_bits == 16) ? 2 : 1; }
     }
     return served(qmg_stencil_apply_epi_t(dt, mat32, &d, lhs, rhs, pieces, stride, system, &epi, qmg::current_stream()), "qmg_stencil_apply_epi_t") != 0;
   }
@@ -784,6 +839,7 @@ struct Stencil2D {
     if (twolink != 0) cout << "[QMG-WARNING]: two link stencil not yet supported.\n";
     if (corner != 0) cout << "[QMG-WARNING]: corner stencil not yet supported.\n";
     built_rbjacobi = true;
+    narrow_rbjacobi_copies();
     // Wilson from the links (set_direct_links) with a real mass and no eo / dof shift: cinv is ONE real number times the identity
     // at every site, and the right-block-Jacobi hops are the stored hops times it -- take the number the build left in cinv
     direct.rbj_scale = 0.0;

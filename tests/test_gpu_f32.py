@@ -243,6 +243,64 @@ def test_fine_apply_with_16_bit_stored_matrices(name, pieces, Lx, Ly):
             assert cs.rel_l2(got[seg], ol.stencil_apply(ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts), rb[seg].copy())) < TOL32
 
 
+@pytest.mark.parametrize("name,pieces", HALF_PIECES)
+@pytest.mark.parametrize("Lx,Ly,nc", [(16, 6, 8), (12, 8, 12), (8, 8, 24), (34, 4, 16)])
+def test_coarse_apply_with_16_bit_stored_matrices(name, pieces, Lx, Ly, nc):
+    """qmg_stencil_apply_mat16_t (kernel B32 with complex<half> matrices widened on their way into LDS; nc a multiple of 4): fp64 vectors against
+    the fp64 oracle on the SAME matrices after rounding to half (1e-13: only summation order differs), complex<float> vectors to 2e-6; a masked
+    batch of 3 (the 4-system pass), a batch of 7 (the 8-system pass), and the MR / residual epilogue (mat32 = 2)."""
+    vol, size = Lx * Ly, Lx * Ly * nc
+    h16 = lambda v: (v.real.astype(np.float16).astype(np.float64) + 1j * v.imag.astype(np.float16).astype(np.float64))
+    clover, hopping = h16(cs.gaussian_cvec(vol * nc * nc, 1)), h16(cs.gaussian_cvec(4 * vol * nc * nc, 2))
+    shifts = (0.3 - 0.1j, 0.05 + 0.02j, -0.07j)
+    od = ol.make_desc(Lx, Ly, nc, clover, hopping, *shifts)
+    dc64, dh64 = qmg.DeviceArray.from_host(clover), qmg.DeviceArray.from_host(hopping)
+    dc, dh = qmg.DeviceArray(vol * nc * nc, np.float32), qmg.DeviceArray(4 * vol * nc * nc, np.float32)      # 4 bytes per complex<half>
+    qmg.convert_to_c16(dc, dc64, qmg.C64, vol * nc * nc)
+    qmg.convert_to_c16(dh, dh64, qmg.C64, 4 * vol * nc * nc)
+    back = qmg.DeviceArray(vol * nc * nc)
+    qmg.convert_from_c16(back, qmg.C64, dc, vol * nc * nc)
+    assert np.array_equal(back.to_host(), clover)                     # the conversion pair is exact on half-representable values
+    gd = qmg.make_desc(Lx, Ly, nc, dc, dh, *shifts)
+    rhs, lhs0 = cs.gaussian_cvec(size, 3), cs.gaussian_cvec(size, 4)
+    want = ol.stencil_apply(od, rhs, pieces, lhs=lhs0.copy())
+    dl = qmg.DeviceArray.from_host(lhs0)
+    assert qmg.stencil_apply_mat16(qmg.C64, gd, dl, qmg.DeviceArray.from_host(rhs), pieces) == 0
+    assert cs.rel_l2(dl.to_host(), want) < 1e-13
+    r32v, l32v = r32(rhs), r32(lhs0)
+    dl32 = D32(l32v)
+    assert qmg.stencil_apply_mat16(qmg.C32, gd, dl32, D32(r32v), pieces) == 0
+    assert cs.rel_l2(H(dl32), ol.stencil_apply(od, r32v, pieces, lhs=l32v.copy())) < 2e-6
+    # batches: 2 of 3 (kernel B32's 4-system pass), 7 (kernel C, packed columns), 12 of 13 (kernel C, plain columns)
+    for nrhs, mask in ((3, 0b101), (7, 0x7F), (13, 0x1FFF & ~0b100)):
+        rb, lb = cs.gaussian_cvec(nrhs * size, 5), cs.gaussian_cvec(nrhs * size, 6)
+        for vdt, tol in ((qmg.C64, 1e-13), (qmg.C32, 2e-6)):
+            rbv, lbv = (rb, lb) if vdt == qmg.C64 else (r32(rb), r32(lb))
+            dlb = qmg.DeviceArray.from_host(lbv) if vdt == qmg.C64 else D32(lbv)
+            drb = qmg.DeviceArray.from_host(rbv) if vdt == qmg.C64 else D32(rbv)
+            assert qmg.stencil_apply_mat16(vdt, gd, dlb, drb, pieces, nrhs=nrhs, vec_stride=size, mask=mask) == 0
+            got = dlb.to_host() if vdt == qmg.C64 else H(dlb)
+            for k in range(nrhs):
+                seg = slice(k * size, (k + 1) * size)
+                if not (mask >> k) & 1:
+                    assert np.array_equal(got[seg], lbv[seg])
+                else:
+                    assert cs.rel_l2(got[seg], ol.stencil_apply(od, rbv[seg].copy(), pieces, lhs=lbv[seg].copy())) < tol, (nrhs, k, vdt)
+    if name == "all_zero":   # epilogue on the 16-bit storage: out = b - A x, and p = A r with the MR dots
+        b = cs.gaussian_cvec(size, 7)
+        out = qmg.DeviceArray.zeros(size)
+        db, dx = qmg.DeviceArray.from_host(b), qmg.DeviceArray.from_host(rhs)
+        assert qmg.stencil_apply_epi(qmg.C64, 2, gd, out, dx, pieces, qmg.make_epilogue(db, 1.0, -1.0, None)) == 0
+        Ax = ol.stencil_apply(od, rhs)
+        assert cs.rel_l2(out.to_host(), b - Ax) < 1e-13
+        assert qmg.stencil_apply_epi(qmg.C64, 2, gd, out, dx, pieces, qmg.make_epilogue(None, 0.0, 1.0, dx)) == 0
+        dots = qmg.batch_mr_read_dots(1)[0]
+        p = out.to_host()
+        assert abs(complex(dots[0], dots[1]) - np.vdot(p, rhs)) <= 1e-12 * abs(np.vdot(p, rhs)) and abs(dots[2] - np.vdot(p, p).real) <= 1e-12 * np.vdot(p, p).real
+    # refused where kernel B32 does not serve the storage
+    assert qmg.stencil_apply_mat16(qmg.C64, qmg.make_desc(8, 8, 6, dc, dh), dl, dl, pieces) == 3
+
+
 @pytest.mark.parametrize("variant", ["", "schur"])
 def test_kcycle_with_16_bit_fine_matrices_still_reaches_fp64_tolerance(golden_dir, variant):
     """QMG_F16_FINE=1: inside the fp32 K-cycle the level-0 matrices are streamed in 16 bits (operator perturbed by ~5e-4);

@@ -192,20 +192,39 @@ def test_n22_four_levels_and_batched_setup(golden_dir):
 
 
 def test_kcycle_with_f32_stored_coarse_operators(golden_dir):
-    """Default of the K-cycle hierarchy (multigrid.hpp; QMG_COARSE_F32=0 switches it off): the Galerkin operators are streamed as
+    """Default of the K-cycle hierarchy (multigrid.hpp; QMG_COARSE_F32=0 / QMG_COARSE_BITS=64 switch it off): the Galerkin operators are streamed as
     complex<float>; the hierarchy only preconditions, so the outer fp64 VPGCR still reaches 1e-10 in (about) the same number
-    of iterations as with fp64-stored coarse matrices."""
+    of iterations as with fp64-stored coarse matrices.  QMG_COARSE_BITS=16 (opt-in): complex<half> storage (kernel B32 / C widen the tile on its
+    way into LDS), same bar."""
     gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
     its = {}
-    for tag, extra in (("f64", {"QMG_COARSE_F32": "0"}), ("f32", {})):
+    for tag, extra in (("f64", {"QMG_COARSE_F32": "0"}), ("f32", {}), ("f16", {"QMG_COARSE_BITS": "16"})):
         out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle_mrhs"), "128", "-0.07", "6.0", "2", "8", gauge_file, "64", "3", "verify"],
                              cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", **extra), capture_output=True, text=True, timeout=150)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-        assert ("complex<float>" in out.stdout) == (tag == "f32")
+        assert ("complex<float>" in out.stdout) == (tag == "f32") and ("complex<half>" in out.stdout) == (tag == "f16")
         rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
         assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows)
         its[tag] = [int(r[1]) for r in rows]
-    assert all(abs(a - b) <= 2 for a, b in zip(its["f64"], its["f32"])), its
+    assert all(abs(a - b) <= 2 and abs(a - c) <= 2 for a, b, c in zip(its["f64"], its["f32"], its["f16"])), its
+
+
+def test_schur_kcycle_with_narrow_stored_rbjacobi_operators(golden_dir):
+    """The red-black (Schur) K-cycle streams the right-block-Jacobi hops and cinv, not the ORIGINAL arrays: a preconditioner hierarchy keeps
+    complex<float> (default) or complex<half> (QMG_COARSE_BITS=16) copies of those as well (Stencil2D::narrow_rbjacobi_copies).  n22 in its
+    Schur form at 256^2 (4 levels), 24 coarse dof: the same outer iterations (+-1) and the ORIGINAL system's true residual <= 1e-10 with
+    fp64, fp32 and 16-bit storage."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    its = {}
+    for tag, bits in (("f64", "64"), ("f32", "32"), ("f16", "16")):
+        out = subprocess.run([os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "3", "1", gauge_file, "64", "schur"], cwd=DRIVERS,
+                             env=dict(os.environ, QMG_QUIET="1", QMG_COARSE_BITS=bits), capture_output=True, text=True, timeout=200)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+        assert ("as complex<float>" in out.stdout) == (tag == "f32") and ("as complex<half>" in out.stdout) == (tag == "f16")
+        its[tag] = int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1))
+        assert float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1)) <= 1.05e-10
+    assert abs(its["f32"] - its["f64"]) <= 1 and abs(its["f16"] - its["f64"]) <= 1, its
 
 
 def test_cgne_smoothers_in_both_engines(golden_dir):
