@@ -189,11 +189,14 @@ static PassIds make_pass(const BatchIdx& bi, int s0) {
 // of each d as LDS broadcasts (all lanes of a site read the same address; the site stride is padded so that different
 // sites of a row hit different banks).  (The first version looped 8 x nvec coarse values per element through L1:
 // address-bound at 2 TB/s, profiles/r01_kernel_rooflines.json.)
-template <typename T, int KB>
+template <typename T, int KB, int NVB = 4>
 __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse, void* __restrict__ fine,
                                                          const XferGeom g, const PassIds ids, long cstride, long fstride, int SX) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  cplx* cl = reinterpret_cast<cplx*>(smem_raw);          // [SX][nvec * KB + 1]
+  // the coarse tile in the vectors' STORAGE type: complex<float> systems keep 8-byte entries (the 8-system form reads nvec x 8 of them per fine
+  // element: at 16 bytes each the LDS reads were a third of the kernel's time), widened when they are multiplied
+  typedef typename CStore<T>::type lt;
+  lt* cl = reinterpret_cast<lt*>(smem_raw);          // [SX][nvec * KB + 1]
   const int ns = (ids.n < KB) ? ids.n : KB;
   const int G = (g.bx / 2) * g.fnc, R = 2 * g.by;
   const int cLx = 2 * g.chr;
@@ -208,7 +211,9 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
     for (int t = threadIdx.x; t < nsx * KB * nvec; t += BLOCK) {   // d fastest: coalesced runs of nvec coarse values
       const int d = t % nvec, q = (t / nvec) % KB, s = t / (nvec * KB);
       const long ci = coarse_site_index(g, cx0 + s, cy);
-      cl[s * sstride + d * KB + q] = (q < ns) ? ldc<T>(coarse, (long)pick_id(ids, q) * cstride + ci * g.cnc + d) : cmake(0.0, 0.0);
+      lt cv; cv.x = 0; cv.y = 0;
+      if (q < ns) cv = reinterpret_cast<const lt*>(coarse)[(long)pick_id(ids, q) * cstride + ci * g.cnc + d];
+      cl[s * sstride + d * KB + q] = cv;
     }
     __syncthreads();
     const int row_w = nsx * G;
@@ -216,11 +221,29 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
       const int rr = t / row_w, u = t - rr * row_w, s = u / G;
       const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
       const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx0 * (g.bx / 2)) * g.fnc + u;
-      const cplx* cs = cl + s * sstride;
+      const lt* cs = cl + s * sstride;
+      auto wide = [](const lt v) { return cmake((double)v.x, (double)v.y); };
       cplx acc[KB];
 #pragma unroll
       for (int q = 0; q < KB; q++) acc[q] = ldc<T>(fine, fo[q] + e);
       int d = 0;
+      // NVB null-vector entries requested together and kept in their STORAGE type until they are used: a thread has NVB x 8 (complex<float>) or
+      // NVB x 16 bytes in flight; with 4 of them the complex<float> form had 32 B per thread outstanding and ran at 0.42-0.48 of the HBM rate
+      // (NVB = 12 is instantiated for complex<float> with >= 12 null vectors: 2048^2 -> 512^2 x 24, 8 systems 0.90 -> 0.82 ms, 512^2 -> 128^2 0.58 -> 0.47;
+      // compiled into the nvec = 8 launches as well it cost them a wavefront of occupancy: 1.88 -> 2.14 ms)
+      if constexpr (sizeof(T) == 4 && NVB > 4) {
+        for (; d + NVB <= nvec; d += NVB) {
+          long long nv[NVB];   // raw bits of a complex<float>
+#pragma unroll
+          for (int w = 0; w < NVB; w++) nv[w] = __builtin_nontemporal_load(reinterpret_cast<const long long*>(nullv) + (long)(d + w) * g.fsize + e);
+#pragma unroll
+          for (int w = 0; w < NVB; w++) {
+            const cplx nw = cmake((double)__int_as_float((int)(nv[w] & 0xFFFFFFFFll)), (double)__int_as_float((int)(nv[w] >> 32)));
+#pragma unroll
+            for (int q = 0; q < KB; q++) cmac(acc[q], nw, wide(cs[(d + w) * KB + q]));
+          }
+        }
+      }
       for (; d + 4 <= nvec; d += 4) {
         cplx nv[4];
 #pragma unroll
@@ -228,12 +251,12 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
 #pragma unroll
         for (int w = 0; w < 4; w++)
 #pragma unroll
-          for (int q = 0; q < KB; q++) cmac(acc[q], nv[w], cs[(d + w) * KB + q]);
+          for (int q = 0; q < KB; q++) cmac(acc[q], nv[w], wide(cs[(d + w) * KB + q]));
       }
       for (; d < nvec; d++) {
         const cplx nv = ldc_nt<T>(nullv, (long)d * g.fsize + e);
 #pragma unroll
-        for (int q = 0; q < KB; q++) cmac(acc[q], nv, cs[d * KB + q]);
+        for (int q = 0; q < KB; q++) cmac(acc[q], nv, wide(cs[d * KB + q]));
       }
 #pragma unroll
       for (int q = 0; q < KB; q++)
@@ -540,7 +563,7 @@ static int prolong_tile_sites(const XferGeom& g, int nvec, int KB) {
   int SX = (32 + G - 1) / G;
   if (SX < 1) SX = 1;
   if (SX > 2 * g.chr) SX = 2 * g.chr;
-  while (SX > 1 && (size_t)SX * (nvec * KB + 1) * sizeof(cplx) > 48 * 1024) SX--;
+  while (SX > 1 && (size_t)SX * (nvec * KB + 1) * sizeof(cplx) > 48 * 1024) SX--;   // (sized for complex<double> entries; complex<float> tiles use half of it)
   return SX;
 }
 
@@ -565,10 +588,11 @@ static int prolong_batch_impl(const void* nullvecs, int nvec, const void* coarse
     }
     const int KB = left > 4 ? 8 : left > 2 ? 4 : 2;
     const int SX = prolong_tile_sites(g, nvec, KB);
-    const size_t smem = (size_t)SX * (nvec * KB + 1) * sizeof(cplx);
+    const size_t smem = (size_t)SX * (nvec * KB + 1) * sizeof(ct);
     if (smem > 64 * 1024) return QMG_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((2 * g.chr + SX - 1) / SX), g.cLy > 65535 ? 65535 : g.cLy);
-    if (KB == 8) k_bprolong_tile<T, 8><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
+    if (KB == 8 && sizeof(T) == 4 && nvec >= 12) k_bprolong_tile<T, 8, 12><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
+    else if (KB == 8) k_bprolong_tile<T, 8><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
     else if (KB == 4) k_bprolong_tile<T, 4><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
     else k_bprolong_tile<T, 2><<<grid, BLOCK, smem, st>>>(nullvecs, nvec, coarse, fine, g, make_pass(bi, s0), (long)cstride, (long)fstride, SX);
     QMG_LAUNCH_CHECK();

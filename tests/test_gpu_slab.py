@@ -381,6 +381,36 @@ def test_kcycle_on_slabs_follows_the_single_domain_kcycle(L, levels, nc, R, batc
     assert "world %d" % R in many.stdout
 
 
+@pytest.mark.parametrize("R", [2, 4])
+def test_cgne_smoothers_on_slabs(R):
+    """LevelSolveMG::pre_cgne / post_cgne (stateful_multigrid.h:847-857, 1032-1042) with ONE lattice cut into y-slabs: the dagger stencils of every
+    level are built on the slabs (qmg_build_dagger_slab: the transposed hops across a slab boundary come from the neighbouring rank's rows) and
+    the smoothers run MR on M M^dagger followed by M^dagger through the slab applies.  One rank in slab mode = the plain driver digit for
+    digit; R thread-emulated ranks: the same outer iterations, the same solution norm to 1e-10."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    args = ["128", "-0.05", "6.0", "2", "8", gauge, "64"]
+    env = dict(os.environ, QMG_QUIET="1", QMG_NULL_BATCH="1", QMG_SMOOTHER="cgne")
+    plain = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle")] + args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    for o in (plain, one, many):
+        assert o.returncode == 0 and "CGNE smoothers" in o.stdout, o.stdout[-2500:] + o.stderr[-1500:]
+        assert "[QMG-ERROR]" not in o.stdout and "[QMG-WARNING]" not in o.stdout, o.stdout[-2500:]
+    it = lambda o: int(re.search(r"Multigrid converged in (\d+) iterations", o.stdout).group(1))
+    chk = lambda o: float(re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1))
+    slab = lambda o: [float(v) for v in re.search(r"\[QMG-SLAB\]: world \d+ ; \|b\| ([\d.e+-]+) ; \|x\|\^2 ([\d.e+-]+)", o.stdout).groups()]
+    assert it(one) == it(plain) and chk(one) == chk(plain)
+    assert it(many) == it(one) and chk(many) < 1e-9, (it(many), it(one), chk(many))
+    (b1, x1), (bR, xR) = slab(one), slab(many)
+    assert abs(bR - b1) < 1e-13 * b1 and abs(xR - x1) < 1e-10 * x1, (b1, bR, x1, xR)
+
+
 def test_two_processes_on_one_device_rendezvous_and_are_refused_by_rccl_without_hanging():
     """The launcher path with world = 2 on a one-GPU box: both processes complete the TCP rendezvous of the RCCL id (qmg_comm_init_env),
     then RCCL refuses the second rank on the same device -- and BOTH processes must come back with an error exit in seconds, not
