@@ -323,6 +323,14 @@ def kcycle_c5_schur_and_f32():
             if m2 and it2 and res2:
                 out[key] = {"value": float(m2.group(3)), "outer_iterations": int(it2.group(2)), "converged": it2.group(1) == "converged",
                             "true_residual_original_system": float(res2.group(1)), "solve_s": float(m2.group(2)), "QMG_COARSE_BITS": int(bits)}
+        q = subprocess.run([exe, "4096", str(MASS), "6.0", "3", "1", fixture, "64", "schur", "nrhs=1", "f32"], cwd=drivers, env=dict(os.environ, QMG_QUIET="1", QMG_F16_COARSE="1"),
+                           capture_output=True, text=True, timeout=900)
+        f2 = re.search(r"rhs 0 (converged|failed to converge) in (\d+) iterations ; alleged tolerance [\d.e+-]+ ; check tolerance ([\d.e+-]+)", q.stdout)
+        ft2 = re.search(r"batched solve of 1 systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+)", q.stdout)
+        if f2 and ft2:
+            out["fp32_kcycle_16bit_storage"] = {"value": float(ft2.group(2)), "outer_iterations": int(f2.group(2)), "converged": f2.group(1) == "converged",
+                                                "true_residual_original_system": float(f2.group(3)), "solve_s": float(ft2.group(1)),
+                                                "note": "the complex<float> K-cycle with the Galerkin levels' matrices and right-block-Jacobi hops stored as complex<half> (opt-in, QMG_F16_COARSE=1)"}
         if "fp32_kcycle" in out and "fp64_strict_storage" in out:
             out["fp32_over_fp64_strict_storage"] = out["fp32_kcycle"]["value"] / out["fp64_strict_storage"]["value"]
         return out
@@ -638,7 +646,7 @@ def kcycle_c3(extra_env=None):
         return {"error": repr(e)}
 
 
-def kcycle_c3_batched(nrhs=8, f32=False):
+def kcycle_c3_batched(nrhs=8, f32=False, extra_env=None):
     """The same solve for a lock-step batch of `nrhs` independent right-hand sides on the one GPU (include/qmg/batch.hpp):
     coarse operators / null vectors streamed once per step for the batch, coarse applies on the f64 matrix cores.
     `value` is the aggregate over the batch (sum of the systems' outer iterations / wall).
@@ -653,7 +661,7 @@ def kcycle_c3_batched(nrhs=8, f32=False):
         if not os.path.exists(exe):
             subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
         p = subprocess.run([exe, "2048", str(MASS), "6.0", "2", "24", fixture, "64", str(nrhs)] + (["f32"] if f32 else []), cwd=drivers,
-                           env=dict(os.environ, QMG_QUIET="1"), capture_output=True, text=True, timeout=600)
+                           env=dict(os.environ, QMG_QUIET="1", **(extra_env or {})), capture_output=True, text=True, timeout=600)
         m = re.search(r"setup ([\d.e+-]+) s ; batched solve of (\d+) systems ([\d.e+-]+) s ; aggregate outer iterations/s ([\d.e+-]+) ; systems/s ([\d.e+-]+)", p.stdout)
         rows = re.findall(r"rhs (\d+) (converged|failed to converge) in (\d+) iterations ; alleged tolerance [\d.e+-]+ ; check tolerance ([\d.e+-]+)", p.stdout)
         return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, %s, %d independent right-hand side%s%s on 1 GPU"
@@ -942,6 +950,11 @@ def main():
         if "value" in f1 and "value" in out["also_kcycle"]:
             out["also_kcycle"]["fp32_over_fp64"] = f1["value"] / out["also_kcycle"]["value"]
         out["also_kcycle_batched"]["fp32_kcycle"] = f8
+        # ... and with the Galerkin levels' matrices of that complex<float> K-cycle stored as complex<half> (opt-in, QMG_F16_COARSE=1)
+        h1 = kcycle_c3_batched(1, f32=True, extra_env={"QMG_F16_COARSE": "1"})
+        if "workload" in h1:
+            h1["workload"] += "; coarse-level matrices of the K-cycle stored as complex<half> (QMG_F16_COARSE=1)"
+        out["also_kcycle"]["fp32_kcycle_16bit_storage"] = h1
         out["also_kcycle_c5_shape"] = kcycle_c5_shape()
 
     if not args.no_also:   # every rank takes part: the slabs of one lattice

@@ -35,9 +35,10 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
   if (f32_kcycle) {
     BatchKcycle sh(mg, 1);
     const bool half_fine = getenv("QMG_F16_FINE") != 0;   // level-0 matrices of the fp32 K-cycle in 16 bits
-    if (!sh.enable_f32_hierarchy(half_fine)) { std::cout << "[QMG-ERROR]: could not build the fp32 shadow of the hierarchy\n"; return false; }
+    const bool half_coarse = getenv("QMG_F16_COARSE") != 0;   // the Galerkin levels' matrices of the fp32 K-cycle in 16 bits
+    if (!sh.enable_f32_hierarchy(half_fine, half_coarse)) { std::cout << "[QMG-ERROR]: could not build the fp32 shadow of the hierarchy\n"; return false; }
     cout << "[QMG-INFO]: K-cycle preconditioner in fp32 (complex<float> vectors, matrices and null vectors; fp64 outer VPGCR)"
-         << (half_fine ? "; fine-level matrices of the K-cycle stored in 16 bits" : "") << "\n";
+         << (half_fine ? "; fine-level matrices of the K-cycle stored in 16 bits" : "") << (half_coarse ? "; coarse-level matrices of the K-cycle stored in 16 bits" : "") << "\n";
   }
   // batch size: what fits (an outer solve rarely needs its whole restart length; 48 directions is a safe expectation for
   // these K-cycles, and bgcr_core stops loudly if a basis vector cannot be allocated)

@@ -732,9 +732,10 @@ struct BatchKcycle {
   // complex<float> shadows of every level's matrices and null vectors, for the QMG_C32 K-cycle (the fp64 hierarchy stays
   // the master copy; call again after the hierarchy changes)
   // half_fine: the fine level (nc = 2) additionally keeps its matrices in 16 bits for the K-cycle's own applies (112 B/site)
-  bool enable_f32_hierarchy(bool half_fine = false) {
+  // half_coarse: the Galerkin levels keep theirs (and their right-block-Jacobi hops) in 16 bits as well (kernels B32 / C with complex<half> matrices)
+  bool enable_f32_hierarchy(bool half_fine = false, bool half_coarse = false) {
     const int nl = mg->get_num_levels();
-    for (int i = 0; i < nl; i++) if (!mg->get_stencil(i) || !mg->get_stencil(i)->enable_f32_shadow(half_fine && i == 0)) return false;
+    for (int i = 0; i < nl; i++) if (!mg->get_stencil(i) || !mg->get_stencil(i)->enable_f32_shadow(i == 0 ? half_fine : half_coarse)) return false;
     for (int i = 0; i < nl - 1; i++) if (!mg->get_transfer(i)->enable_f32_shadow()) return false;
     return true;
   }

@@ -285,7 +285,17 @@ struct Stencil2D {
 
   bool enable_f32_shadow(bool half_matrices = false) {
     disable_f32_shadow();
-    if (half_matrices && lat->get_nc() != 2) half_matrices = false;   // the 16-bit kernel serves nc = 2 (the fine Wilson-type operators)
+    // 16-bit matrices: nc = 2 (kernel S, qmg_stencil_apply_h16) or a multiple of 4 beyond 4 (kernels B32 / C, qmg_stencil_apply_mat16_t) with every entry
+    // inside half range
+    if (half_matrices) {
+      const int nc_ = lat->get_nc();
+      if (!(nc_ == 2 || (nc_ > 4 && (nc_ & 3) == 0 && !qmg::slab().on))) half_matrices = false;   // (slabs: the 16-bit slab kernel is kernel S, nc = 2)
+      else if (nc_ != 2) {
+        double big = std::max(clover ? norminf(clover, (size_t)lat->get_size_cm_l()) : 0.0, hopping ? norminf(hopping, (size_t)lat->get_size_hopping_l()) : 0.0);
+        if (built_rbjacobi && rbjacobi_hopping) big = std::max(big, norminf(rbjacobi_hopping, (size_t)lat->get_size_hopping_l()));
+        if (!(big < 6.0e4)) half_matrices = false;
+      }
+    }
     auto dup = [&](void** dst, const complex<double>* src, long n) -> bool {
       if (src == 0) return true;
       if (qmg_malloc(dst, (size_t)n * 8) != QMG_SUCCESS) { *dst = 0; return false; }
@@ -589,7 +599,8 @@ struct Stencil2D {
       if (f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER) {   // 16-bit stored matrices, fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
-        qmg::ok(qmg_stencil_apply_h16(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_h16");
+        if (d.nc == 2) qmg::ok(qmg_stencil_apply_h16(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_h16");
+        else qmg::ok(qmg_stencil_apply_mat16_t(QMG_C32, &d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_mat16_t");
         return;
       }
       d.clover = f32_clover_of(set);
@@ -641,10 +652,17 @@ struct Stencil2D {
     }
     int mat32 = 0;
     if (f) {
-      if (!f32.on || (f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER)) return false;
-      d.clover = f32_clover_of(set);
-      d.hopping = f32_hopping_of(set);
-      mat32 = 1;
+      const bool half = f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER;
+      if (!f32.on || (half && d.nc == 2)) return false;   // (kernel S, the 16-bit nc = 2 kernel, has no epilogue)
+      if (half) {
+        d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
+        d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
+        mat32 = 2;
+      } else {
+        d.clover = f32_clover_of(set);
+        d.hopping = f32_hopping_of(set);
+        mat32 = 1;
+      }
     } else {
       d.clover = clover_of(set);
       d.hopping = hopping_of(set);

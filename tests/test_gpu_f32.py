@@ -307,12 +307,15 @@ def test_kcycle_with_16_bit_fine_matrices_still_reaches_fp64_tolerance(golden_di
     the fp64 outer VPGCR still converges to 1e-10 (true residual of the ORIGINAL fp64 operator) in about the same count."""
     gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
     its = {}
-    for tag, env in (("f32", {}), ("f16", {"QMG_F16_FINE": "1"})):
+    for tag, env in (("f32", {}), ("f16", {"QMG_F16_FINE": "1"}), ("f16c", {"QMG_F16_COARSE": "1"}), ("f16fc", {"QMG_F16_FINE": "1", "QMG_F16_COARSE": "1"})):
         cmd = [os.path.join(DRIVERS, "n22_wilson_kcycle_adaptive"), "256", "-0.07", "6.0", "2", "1", gauge_file, "64", "nrhs=2", "f32"] + ([variant] if variant else [])
         out = subprocess.run(cmd, cwd=DRIVERS, env=dict(os.environ, QMG_QUIET="1", **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-        assert ("stored in 16 bits" in out.stdout) == (tag == "f16")
+        assert "[QMG-ERROR]" not in out.stdout
+        assert ("fine-level matrices of the K-cycle stored in 16 bits" in out.stdout) == ("QMG_F16_FINE" in env)
+        assert ("coarse-level matrices of the K-cycle stored in 16 bits" in out.stdout) == ("QMG_F16_COARSE" in env)     # (kernels B32 / C with complex<half> matrices)
         rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
         assert len(rows) == 2 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-1500:]
         its[tag] = [int(r[1]) for r in rows]
-    assert all(b <= a + max(3, a // 8) for a, b in zip(its["f32"], its["f16"])), its
+    for tag in ("f16", "f16c", "f16fc"):
+        assert all(b <= a + max(3, a // 8) for a, b in zip(its["f32"], its[tag])), its
