@@ -345,7 +345,7 @@ static int run(int proc_rank, int proc_world, int local_rank, bool slab_mode, in
   mg_object->get_stencil(0)->prepare_M(b_prep, b, solve_type);
   const int solve_size = schur ? (int)(n0 / 2) : (int)n0;
 
-  verb.verbosity = quiet ? VERB_SUMMARY : VERB_DETAIL;
+  verb.verbosity = !t_root ? VERB_NONE : quiet ? VERB_SUMMARY : VERB_DETAIL;   // (thread-emulated ranks share one stdout: only the root rank reports, or its lines are torn)
   verb.verb_prefix = "[QMG-MG-SOLVE-INFO]: Level 0 ";
   qmg_reserve_kcycle_scratch(mg_object, (size_t)solve_size, restart_freq);   // the solve's scratch, outside its timed region
   qmg_stream_sync(qmg::current_stream());
