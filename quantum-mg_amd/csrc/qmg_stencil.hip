@@ -783,17 +783,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
 #pragma unroll
       for (int kk = 0; kk < KR; kk++) acc[kk] = cmake(0.0, 0.0);
 
-      // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order
-      const int order[5] = {4, 0, 1, 2, 3};
-      double2 stage[PP];   // raw bits of two complex<float> each
-      cplx xstage[KR];
+      // piece order: clover (4), +x, +y, -x, -y  -- the reference's accumulation order.  The active pieces (uniform over the block) are
+      // walked by a loop the compiler unrolls, so the staging-register sets have compile-time indices: PF pieces are requested ahead of the
+      // one that computes.  PF = 2 for the 16-bit storage: a piece is half the bytes of the fp32 form, so with one piece ahead a block
+      // had half the bytes in flight and the kernel stopped at 0.61 of the HBM rate; two sets of quads cost what one set of pairs does.
+      constexpr int PF = M16 ? 2 : 1;
+      double2 stage[PF][PP];   // raw bits of two complex<float> (four complex<half>) each
+      cplx xstage[PF][KR];
 #pragma unroll
-      for (int kk = 0; kk < KR; kk++) xstage[kk] = cmake(0.0, 0.0);
-      int cur = -1;
-      // find first active piece and prefetch it
-      int oi = 0;
-      while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
-      auto prefetch = [&](int piece) {
+      for (int f = 0; f < PF; f++)
+#pragma unroll
+        for (int kk = 0; kk < KR; kk++) xstage[f][kk] = cmake(0.0, 0.0);
+      // bit oi of om: the oi-th piece of the order {clover, +x, +y, -x, -y} is active
+      unsigned om = ((piece_mask >> 4) & 1u) | ((piece_mask & 0xFu) << 1);
+      const int npc = __popc(om);
+      int lst[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) { const int oi = om ? __ffs(om) - 1 : 0; lst[i] = (oi == 0) ? 4 : oi - 1; om &= om - 1; }
+      auto prefetch = [&](int piece, int f) {
         const cplx* mbase = (piece == 4) ? a.clover : a.hopping;                 // (element offsets, so that the same
         long moff = (piece == 4) ? site0 * nc2 : (long)piece * a.size_cm + site0 * nc2;   //  code serves both matrix widths)
         const int lim = nsite * (int)nc2;
@@ -804,9 +811,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           const int el = (M16 ? 4 : 2) * (tid + q * BLOCK);
           if (el < lim) {
             const double* pp = M16 ? reinterpret_cast<const double*>(m16 + el) : reinterpret_cast<const double*>(m32 + el);
-            stage[q].x = __builtin_nontemporal_load(pp);
-            stage[q].y = __builtin_nontemporal_load(pp + 1);
-          } else stage[q] = make_double2(0.0, 0.0);
+            stage[f][q].x = __builtin_nontemporal_load(pp);
+            stage[f][q].y = __builtin_nontemporal_load(pp + 1);
+          } else stage[f][q] = make_double2(0.0, 0.0);
         }
         // neighbour vector element for (site, c) = tid / nc, tid % nc
         if (tid < nsite * nc) {
@@ -820,12 +827,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           else nbsite = opp + (long)ym * a.hr + j;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+            if (kk < nk) xstage[f][kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
         }
       };
-      if (oi < 5) { cur = order[oi]; prefetch(cur); }
+#pragma unroll
+      for (int i = 0; i < PF; i++)
+        if (i < npc) prefetch(lst[i], i);
 
-      while (cur >= 0) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        if (i < npc) {
+        const int f = i % PF;
         __syncthreads();   // previous compute finished reading LDS
         // registers -> LDS (padded rows)
 #pragma unroll
@@ -836,23 +848,20 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
             if constexpr (M16) {
               typedef _Float16 h8 __attribute__((ext_vector_type(8)));
               typedef float f4 __attribute__((ext_vector_type(4)));
-              const h8 hv = __builtin_bit_cast(h8, stage[q]);   // (re, im) x 4
+              const h8 hv = __builtin_bit_cast(h8, stage[f][q]);   // (re, im) x 4
               const f4 w0 = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}, w1 = {(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
               *reinterpret_cast<f4*>(mlds + (size_t)rowi * rs32 + cc) = w0;
               *reinterpret_cast<f4*>(mlds + (size_t)rowi * rs32 + cc + 2) = w1;
             } else
-              *reinterpret_cast<double2*>(mlds + (size_t)rowi * rs32 + cc) = stage[q];
+              *reinterpret_cast<double2*>(mlds + (size_t)rowi * rs32 + cc) = stage[f][q];
           }
         }
         if (tid < L.S * nc) {
 #pragma unroll
-          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[kk];
+          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[f][kk];
         }
-        // issue the next piece's global loads before computing on this one
-        int nxt = -1;
-        oi++;
-        while (oi < 5 && !((piece_mask >> order[oi]) & 1u)) oi++;
-        if (oi < 5) { nxt = order[oi]; prefetch(nxt); }
+        // issue the global loads of the piece PF ahead (into the set just parked) before computing on this one
+        if (i + PF < npc) prefetch(lst[i + PF], f);
         __syncthreads();
         if (worker && s_of < nsite && !QMG_ABLATE(a, 32)) {
           const float2* mrow = mlds + (size_t)sr * rs32;
@@ -864,8 +873,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
             for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
           }
         }
-        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
-        cur = nxt;
+        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[f][0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
+        }
       }
 
       // shift term needs the own-site vector
