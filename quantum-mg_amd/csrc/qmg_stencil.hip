@@ -949,8 +949,15 @@ __device__ __forceinline__ void wave_lds_handoff() {
 //         24 complex rows waste a quarter of two), nc = 8: 4 instead of 8.  At 16 systems the kernel is MFMA-bound, so that is its time.
 // M16 (with M32): the matrices are stored as complex<half> (NC % 4 == 0): a lane's 16-B load carries four elements, widened to the complex<float>
 // tile when they are parked; everything behind the tile is the M32 form.
+// (-DQMG_KC_F32_PF2=1: the all-complex<float> MODE 1 form with two pieces of prefetch under a 128-register cap (4 wavefronts per SIMD): nc = 24
+// spills 16 registers and goes 1.44 -> 1.61 ms, nc = 12 / 16 within 4 %.  With complex<half> matrices and complex<float> vectors the same
+// launch takes 1.21 ms for HALF the matrix bytes: at 8 systems the kernel's floor is its per-piece chain of LDS hand-offs and dependent MFMAs
+// (four accumulators), not the stream.)
+#ifndef QMG_KC_F32_PF2
+#define QMG_KC_F32_PF2 0
+#endif
 template <int NC, int MODE, bool M32, bool V32, bool VL, bool M16 = false>
-__global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
+__global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 && NC <= 24) ? 4 : (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
   static_assert(MODE != 2 || (VL && !M32 && NC % 2 == 0), "MODE 2: fp64, right-hand sides through the LDS slice");
   static_assert(!M16 || (M32 && NC % 4 == 0), "16-bit matrices: the fp32 tile path, quads that stay inside a row");
   constexpr int RT = (MODE == 2) ? (2 * NC + 15) / 16 : (NC + 15) / 16, KS = (MODE == 2) ? NC / 2 : (NC + 3) / 4;
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 1 && NC <= 24) ? 3 : 1) void k_sten
 #define QMG_KC_PFD_B 1
 #define QMG_KC_PFD_C 1
 #endif
-    constexpr int PFD = (NGS <= 1) ? QMG_KC_PFD_A : (NGS <= 3) ? QMG_KC_PFD_B : (NGS <= 5) ? QMG_KC_PFD_C : 1;
+    constexpr int PFD = (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 && NC <= 24 && NGS <= 5) ? 2 : (NGS <= 1) ? QMG_KC_PFD_A : (NGS <= 3) ? QMG_KC_PFD_B : (NGS <= 5) ? QMG_KC_PFD_C : 1;
     cplx G[PFD][NGS];   // M32: raw bits of two complex<float> per entry
     // Right-hand sides.  VL = false (round 1): each lane loads its B-operand entries X_k[4q + lq] straight from global memory --
     // 16 right-hand sides x 64-byte pieces per instruction, 16 cache lines touched per load, 6 loads per piece; going from 4
