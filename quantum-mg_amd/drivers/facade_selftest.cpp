@@ -238,6 +238,12 @@ int main(int argc, char** argv) {
     zero_vector(a2, ncv); co.apply_M(a2, v);
     const double d32 = sqrt(diffnorm2sq(a1, a2, ncv) / norm2sq(a2, ncv));
     check(d32 > 0.0 && d32 < 1e-6, "apply_M with fp32-stored matrices is the fp64 apply to fp32 rounding", d32);
+    // complex<half> storage (opt-in): nc = 8 qualifies (a multiple of 4, entries inside half range); the apply is the fp64 apply to half rounding
+    const bool f16on = co.enable_f32_matrices(16);
+    zero_vector(a1, ncv); co.apply_M(a1, v);
+    const double d16 = sqrt(diffnorm2sq(a1, a2, ncv) / norm2sq(a2, ncv));
+    check(f16on && co.f32_bits == 16 && d16 > 1e-6 && d16 < 2e-3, "apply_M with 16-bit-stored matrices is the fp64 apply to half rounding", d16);
+    co.disable_f32_matrices();
     for (complex<double>** p : {&v, &a1, &a2}) deallocate_vector(p);
     for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
     delete[] nv;
