@@ -436,6 +436,7 @@ int qmg_wilson_hops_direct(int dtype, const qmg_stencil_desc* d, const void* gau
  *   "site_block"    threads per block of the site kernel: 64, 128 or 256 (256); "site_gy": cap on its grid.y, 0 = rows (0);
  *                   "site_generic": 1 = its run-time-flag variant instead of the compile-time piece shapes (0)
  *   "mfma_vl"       kernel C: right-hand sides through an LDS slice (coalesced loads / stores) (1)
+ *   "mfma_pair8"    kernel C at nc = 8 with 5-8 systems: a wavefront owns two adjacent sites (block-diagonal 16 x 16 tile) (1)
  *   "wilson_pair"   the full Wilson operator from the links: 0 = one site per lane group (kernel W), 1 = both parities of a column
  *                   (kernel W2), 2 = W2 on two rows per lane group for one system on an even run of rows, else as 1 (2)
  *   "xfer_pack"     1: complex<float> single-system restrict / prolong move two elements per lane (16-byte accesses) (1)

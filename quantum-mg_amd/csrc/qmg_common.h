@@ -136,6 +136,52 @@ __device__ __forceinline__ cplx ldc_nt(const void* base, long i) {
   const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long*>(base) + i);
   return make_double2((double)__int_as_float((int)(raw & 0xFFFFFFFFll)), (double)__int_as_float((int)(raw >> 32)));
 }
+// ---- loads that keep the STORAGE form.  A conversion, mask or shift placed right behind a load makes the compiler wait for that load -- and, the
+// counter being in-order, for every load issued before it -- on the spot: a loop of `value = widen(load)` runs one memory latency per element
+// (seen in the ISA of every complex<float> kernel written that way: load, s_waitcnt vmcnt(0), convert, load, ...).  Staging code therefore
+// loads RAW values first (all of them), and widens them where they are consumed.
+template <typename T> struct RawC { typedef cplx type; };            // complex<double>: the value itself
+template <> struct RawC<float> { typedef long long type; };          // the raw bits of a complex<float>
+template <typename T> __device__ __forceinline__ typename RawC<T>::type ld_raw(const void* base, long i) {
+  if constexpr (sizeof(T) == 8) return reinterpret_cast<const cplx*>(base)[i];
+  else return reinterpret_cast<const long long*>(base)[i];
+}
+template <typename T> __device__ __forceinline__ typename RawC<T>::type ld_raw_nt(const void* base, long i) {
+  if constexpr (sizeof(T) == 8) {
+    const cplx* p = reinterpret_cast<const cplx*>(base) + i;
+    cplx v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  } else return __builtin_nontemporal_load(reinterpret_cast<const long long*>(base) + i);
+}
+template <typename T> __device__ __forceinline__ typename RawC<T>::type zero_rawc() {
+  if constexpr (sizeof(T) == 8) return make_double2(0.0, 0.0);
+  else return 0ll;
+}
+template <typename T> __device__ __forceinline__ cplx widen_rawc(typename RawC<T>::type r) {
+  if constexpr (sizeof(T) == 8) return r;
+  else return make_double2((double)__int_as_float((int)(r & 0xFFFFFFFFll)), (double)__int_as_float((int)(r >> 32)));
+}
+// W consecutive elements as ONE 16-byte raw value ((double, 1) and (float, 2)), or (float, 1) as 8 bytes
+template <typename T, int W> struct RawP { typedef typename RawC<T>::type type; };
+template <> struct RawP<float, 2> { typedef float type __attribute__((ext_vector_type(4))); };
+template <typename T, int W> __device__ __forceinline__ typename RawP<T, W>::type ld_rawp(const void* base, long ipack) {
+  if constexpr (sizeof(T) == 4 && W == 2) return reinterpret_cast<const typename RawP<float, 2>::type*>(base)[ipack];
+  else return ld_raw<T>(base, ipack);
+}
+template <typename T, int W> __device__ __forceinline__ typename RawP<T, W>::type ld_rawp_nt(const void* base, long ipack) {
+  if constexpr (sizeof(T) == 4 && W == 2) return __builtin_nontemporal_load(reinterpret_cast<const typename RawP<float, 2>::type*>(base) + ipack);
+  else return ld_raw_nt<T>(base, ipack);
+}
+template <typename T, int W> __device__ __forceinline__ void widen_rawp(typename RawP<T, W>::type r, cplx (&v)[W]) {
+  if constexpr (sizeof(T) == 4 && W == 2) { v[0] = make_double2((double)r.x, (double)r.y); v[W - 1] = make_double2((double)r.z, (double)r.w); }
+  else v[0] = widen_rawc<T>(r);
+}
+template <typename T, int W> __device__ __forceinline__ typename RawP<T, W>::type zero_rawp() {
+  if constexpr (sizeof(T) == 4 && W == 2) { typename RawP<float, 2>::type z = {0.0f, 0.0f, 0.0f, 0.0f}; return z; }
+  else return zero_rawc<T>();
+}
 template <typename T>
 __device__ __forceinline__ void stc(void* base, long i, cplx v) {
   if (sizeof(T) == 8) reinterpret_cast<cplx*>(base)[i] = v;

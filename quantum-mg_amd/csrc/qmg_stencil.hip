@@ -73,10 +73,11 @@ struct StencilArgs {
 #define QMG_ABLATE(a, bits) 0
 #endif
 
-__device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)(a.use_idx ? (int)a.ridx[k] : k) * a.vec_stride; }
-// the same index for a PER-LANE k without touching memory: a.ridx[k] with a divergent k is a vector load from the kernel-argument segment,
-// and an address that waits for it puts a second memory latency in front of every vector load it feeds (kernel C: in front of every piece).
-// The sixteen bytes are four scalar registers; the lane picks its byte with selects and a shift.
+// The system a launch's k-th right-hand side belongs to (masked batches process a subset: a.ridx), WITHOUT touching memory: a.ridx[k] with a
+// run-time k -- divergent or uniform -- is a vector load from the kernel-argument segment, and the `s_waitcnt vmcnt(0)` in front of its use also
+// waits for every load issued before it: in kernels B / B32 that was the next piece's matrix prefetch, issued a few instructions earlier (the
+// wavefront then sat out the whole latency before it computed on the current piece), in kernel C one more memory latency in front of every
+// piece.  The sixteen bytes are four scalar registers; a lane picks its byte with selects and a shift.
 __device__ __forceinline__ int system_index(const StencilArgs& a, int k) {
   if (!a.use_idx) return k;
   unsigned w[4];
@@ -84,10 +85,27 @@ __device__ __forceinline__ int system_index(const StencilArgs& a, int k) {
   const unsigned ww = (k & 8) ? ((k & 4) ? w[3] : w[2]) : ((k & 4) ? w[1] : w[0]);
   return (int)((ww >> (8 * (k & 3))) & 0xffu);
 }
+__device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)system_index(a, k) * a.vec_stride; }
 
 // vector element i of a complex<double> (V32 = false) or complex<float> (V32 = true) array, in fp64 registers
 template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i) { return V32 ? ldc<float>(base, i) : ldc<double>(base, i); }
 template <bool V32> __device__ __forceinline__ void stv(void* base, long i, cplx v) { if (V32) stc<float>(base, i, v); else stc<double>(base, i, v); }
+// A vector element in its STORAGE form (V32: the raw bits of a complex<float> in a double) and its widening.  Staging registers hold the raw
+// form: a conversion right behind the load makes the compiler wait for that load -- and for everything issued before it -- on the spot.
+template <bool V32> struct XRaw { typedef cplx type; };
+template <> struct XRaw<true> { typedef double type; };
+template <bool V32> __device__ __forceinline__ typename XRaw<V32>::type ldv_raw(const void* base, long i) {
+  if constexpr (V32) return reinterpret_cast<const double*>(base)[i];
+  else return reinterpret_cast<const cplx*>(base)[i];
+}
+template <bool V32> __device__ __forceinline__ cplx widen_raw(typename XRaw<V32>::type v) {
+  if constexpr (V32) { struct F2 { float x, y; }; const F2 f = __builtin_bit_cast(F2, v); return cmake((double)f.x, (double)f.y); }
+  else return v;
+}
+template <bool V32> __device__ __forceinline__ typename XRaw<V32>::type zero_raw() {
+  if constexpr (V32) return 0.0;
+  else return cmake(0.0, 0.0);
+}
 
 // the epilogue of one output element (qmg_common.h: Epilogue): returns the value to store, accumulates the MR dots of the value AS STORED
 // ov / r: the element's `other` / `dotv` values, loaded by the caller at the START of the row (a load issued here, after the tile loop,
@@ -142,6 +160,24 @@ __device__ __forceinline__ cplx ldm(const cplx* base, long i) {
   return ld<NT>(base + i);
 }
 
+// a matrix element in its STORAGE form (M32: the raw 8 bytes of a complex<float>) -- staging registers hold this, the widening happens where the
+// element is parked (qmg_common.h: a conversion behind each load serialises the loads)
+template <bool M32> struct MRaw { typedef cplx type; };
+template <> struct MRaw<true> { typedef long long type; };
+template <bool M32, bool NT> __device__ __forceinline__ typename MRaw<M32>::type ldm_raw(const cplx* base, long i) {
+  if constexpr (M32) {
+    const long long* p = reinterpret_cast<const long long*>(base) + i;
+    return NT ? __builtin_nontemporal_load(p) : *p;
+  } else return ld<NT>(base + i);
+}
+template <bool M32> __device__ __forceinline__ cplx widen_mraw(typename MRaw<M32>::type r) {
+  if constexpr (M32) return make_double2((double)__int_as_float((int)(r & 0xFFFFFFFFll)), (double)__int_as_float((int)(r >> 32)));
+  else return r;
+}
+template <bool M32> __device__ __forceinline__ typename MRaw<M32>::type zero_mraw() {
+  if constexpr (M32) return 0ll;
+  else return make_double2(0.0, 0.0);
+}
 // two consecutive complex<float> matrix elements (16 B, element index i even) widened to fp64
 template <bool NT>
 __device__ __forceinline__ void ldm32_pair(const cplx* base, long i, cplx& v0, cplx& v1) {
@@ -591,10 +627,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
       // loads the same number of load instructions moved half the bytes and the apply got no faster
       constexpr int PTS = PT + (PT & 1);
       const bool pairs = M32 && !(nc & 1);
-      cplx stage[PTS];
-      cplx xstage[KR];
+      typename MRaw<M32>::type stage[PTS];            // storage form (widened when parked)
+      typename XRaw<V32>::type xstage[KR];
 #pragma unroll
-      for (int kk = 0; kk < KR; kk++) xstage[kk] = cmake(0.0, 0.0);
+      for (int kk = 0; kk < KR; kk++) xstage[kk] = zero_raw<V32>();
       int cur = -1;
       // find first active piece and prefetch it
       int oi = 0;
@@ -614,14 +650,21 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 #pragma unroll
           for (int q = 0; q < PTS / 2; q++) {
             const int el = 2 * (tid + q * BLOCK);
-            if (el < lim) ldm32_pair<true>(mbase, moff + el, stage[2 * q], stage[2 * q + 1]);
-            else { stage[2 * q] = cmake(0.0, 0.0); stage[2 * q + 1] = cmake(0.0, 0.0); }
+            stage[2 * q] = zero_mraw<M32>(); stage[2 * q + 1] = zero_mraw<M32>();
+            if (el < lim) {
+              if constexpr (M32) {   // 16 bytes: two raw elements
+                const long long* pp = reinterpret_cast<const long long*>(mbase) + moff + el;
+                stage[2 * q] = __builtin_nontemporal_load(pp);
+                stage[2 * q + 1] = __builtin_nontemporal_load(pp + 1);
+              }
+            }
           }
         } else {
 #pragma unroll
           for (int q = 0; q < PT; q++) {
             const int el = tid + q * BLOCK;
-            stage[q] = (el < lim) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
+            stage[q] = zero_mraw<M32>();
+            if (el < lim) stage[q] = ldm_raw<M32, true>(mbase, moff + el);
           }
         }
         // neighbour vector element for (site, c) = tid / nc, tid % nc
@@ -640,10 +683,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
             if (kk < nk) {
-              const int ks = a.use_idx ? (int)a.ridx[k0 + kk] : k0 + kk;
-              if (hi) xstage[kk] = ldv<V32>(a.halo_hi, (long)ks * a.halo_stride + hsite * nc + cc);
-              else if (lo) xstage[kk] = ldv<V32>(a.halo_lo, (long)ks * a.halo_stride + hsite * nc + cc);
-              else xstage[kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+              const int ks = system_index(a, k0 + kk);
+              if (hi) xstage[kk] = ldv_raw<V32>(a.halo_hi, (long)ks * a.halo_stride + hsite * nc + cc);
+              else if (lo) xstage[kk] = ldv_raw<V32>(a.halo_lo, (long)ks * a.halo_stride + hsite * nc + cc);
+              else xstage[kk] = ldv_raw<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
             }
         }
       };
@@ -658,8 +701,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
             const int el = 2 * (tid + q * BLOCK);
             if (el < L.mat_elems) {   // (mat_elems and nc even: the pair never straddles a row)
               const int rowi = el / nc, cc = el - rowi * nc;
-              mlds[(size_t)rowi * L.rs + cc] = stage[2 * q];
-              mlds[(size_t)rowi * L.rs + cc + 1] = stage[2 * q + 1];
+              mlds[(size_t)rowi * L.rs + cc] = widen_mraw<M32>(stage[2 * q]);
+              mlds[(size_t)rowi * L.rs + cc + 1] = widen_mraw<M32>(stage[2 * q + 1]);
             }
           }
         } else {
@@ -668,13 +711,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
             const int el = tid + q * BLOCK;
             if (el < L.mat_elems) {
               const int rowi = el / nc, cc = el - rowi * nc;
-              mlds[(size_t)rowi * L.rs + cc] = stage[q];
+              mlds[(size_t)rowi * L.rs + cc] = widen_mraw<M32>(stage[q]);
             }
           }
         }
         if (tid < L.S * nc) {
 #pragma unroll
-          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[kk];
+          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = widen_raw<V32>(xstage[kk]);
         }
         // issue the next piece's global loads before computing on this one
         int nxt = -1;
@@ -691,7 +734,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen(const StencilArgs a, cons
             for (int kk = 0; kk < KR; kk++) cmac(acc[kk], m, xs[kk * rows + cc]);
           }
         }
-        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[0]);   // diagnostic: no LDS reads / FMAs, loads kept alive
+        if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], widen_mraw<M32>(stage[0]));   // diagnostic: no LDS reads / FMAs, loads kept alive
         cur = nxt;
       }
 
@@ -789,11 +832,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
       // had half the bytes in flight and the kernel stopped at 0.61 of the HBM rate; two sets of quads cost what one set of pairs does.
       constexpr int PF = M16 ? 2 : 1;
       double2 stage[PF][PP];   // raw bits of two complex<float> (four complex<half>) each
-      cplx xstage[PF][KR];
+      typename XRaw<V32>::type xstage[PF][KR];   // (storage form: widened when they are parked)
 #pragma unroll
       for (int f = 0; f < PF; f++)
 #pragma unroll
-        for (int kk = 0; kk < KR; kk++) xstage[f][kk] = cmake(0.0, 0.0);
+        for (int kk = 0; kk < KR; kk++) xstage[f][kk] = zero_raw<V32>();
       // bit oi of om: the oi-th piece of the order {clover, +x, +y, -x, -y} is active
       unsigned om = ((piece_mask >> 4) & 1u) | ((piece_mask & 0xFu) << 1);
       const int npc = __popc(om);
@@ -827,17 +870,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           else nbsite = opp + (long)ym * a.hr + j;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[f][kk] = ldv<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+            if (kk < nk) xstage[f][kk] = ldv_raw<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
         }
       };
-#pragma unroll
-      for (int i = 0; i < PF; i++)
-        if (i < npc) prefetch(lst[i], i);
-
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        if (i < npc) {
-        const int f = i % PF;
+      // one piece: park set f (registers -> LDS), request piece `nextp` into the set just freed, compute
+      auto do_piece = [&](int nextp, auto fc) {
+        constexpr int f = decltype(fc)::value;
         __syncthreads();   // previous compute finished reading LDS
         // registers -> LDS (padded rows)
 #pragma unroll
@@ -858,10 +896,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
         }
         if (tid < L.S * nc) {
 #pragma unroll
-          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = xstage[f][kk];
+          for (int kk = 0; kk < KR; kk++) xlds[kk * rows + tid] = widen_raw<V32>(xstage[f][kk]);
         }
         // issue the global loads of the piece PF ahead (into the set just parked) before computing on this one
-        if (i + PF < npc) prefetch(lst[i + PF], f);
+        if (nextp >= 0) prefetch(nextp, f);
         __syncthreads();
         if (worker && s_of < nsite && !QMG_ABLATE(a, 32)) {
           const float2* mrow = mlds + (size_t)sr * rs32;
@@ -874,7 +912,32 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           }
         }
         if (QMG_ABLATE(a, 32)) acc[0] = cadd(acc[0], stage[f][0]);   // diagnostic: no LDS reads / FMAs, loads kept alive (raw bits)
+      };
+      if constexpr (PF == 1 && PP > 4) {
+        // one piece ahead, large tiles (nc = 24: six staged pairs per thread): a plain loop.  Unrolled over the five pieces -- which is what the
+        // smaller tiles get below: nc = 8, complex<float> vectors 185 -> 168 us per level-1 Schur hop of the C5 solve -- the compiler keeps every
+        // piece's load addresses live: 89 -> 150 VGPRs, 171 with the epilogue, two wavefronts per SIMD instead of four, and the level-1 applies
+        // of the C3 solve went 1.04 -> 1.15 ms.
+        unsigned rest = ((piece_mask >> 4) & 1u) | ((piece_mask & 0xFu) << 1);
+        auto pop = [&]() -> int { if (!rest) return -1; const int oi = __ffs(rest) - 1; rest &= rest - 1; return (oi == 0) ? 4 : oi - 1; };
+        int cur = pop();
+        if (cur >= 0) prefetch(cur, 0);
+        while (cur >= 0) {
+          const int nxt = pop();
+          do_piece(nxt, std::integral_constant<int, 0>());
+          cur = nxt;
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PF; i++)
+          if (i < npc) prefetch(lst[i], i);
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+          if (i < npc) {
+            const int nextp = (i + PF < npc) ? lst[i + PF] : -1;
+            if (i % PF == 0) do_piece(nextp, std::integral_constant<int, 0>());
+            else do_piece(nextp, std::integral_constant<int, PF - 1>());
+          }
       }
 
       // shift term needs the own-site vector
@@ -956,25 +1019,36 @@ __device__ __forceinline__ void wave_lds_handoff() {
 #ifndef QMG_KC_F32_PF2
 #define QMG_KC_F32_PF2 0
 #endif
-template <int NC, int MODE, bool M32, bool V32, bool VL, bool M16 = false>
+// PAIR (NC = 16, MODE 1, VL): the wavefront owns TWO adjacent nc = 8 sites of a row.  Their 8 x 8 matrices sit on the diagonal of the 16 x 16
+// tile (the off-diagonal blocks are zeroed once and never written), their vectors side by side in the 16-wide vector slice -- the two sites'
+// own-site and y-neighbour vectors are contiguous in memory, the x-neighbours are found per lane (they wrap at the row ends).  Same MFMA
+// count per site as the one-site form (a 16-row tile is half empty at nc = 8 either way), HALF the loads, LDS hand-offs and address
+// arithmetic per site: at nc = 8 the one-site form is bound by its instruction issue, not by the stream or the matrix pipe.
+template <int NC, int MODE, bool M32, bool V32, bool VL, bool M16 = false, bool PAIR = false>
 __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 && NC <= 24) ? 4 : (MODE == 1 && NC <= 24) ? 3 : 1) void k_stencil_mfma(const StencilArgs a, const int nk) {
   static_assert(MODE != 2 || (VL && !M32 && NC % 2 == 0), "MODE 2: fp64, right-hand sides through the LDS slice");
   static_assert(!M16 || (M32 && NC % 4 == 0), "16-bit matrices: the fp32 tile path, quads that stay inside a row");
+  static_assert(!PAIR || (NC == 16 && MODE == 1 && VL), "PAIR: two nc = 8 sites, packed columns, vectors through the LDS slice");
+  constexpr int SNC = PAIR ? NC / 2 : NC;            // colours of ONE site
+  constexpr int MEL = PAIR ? 2 * SNC * SNC : NC * NC;   // stored matrix elements per piece per wavefront
   constexpr int RT = (MODE == 2) ? (2 * NC + 15) / 16 : (NC + 15) / 16, KS = (MODE == 2) ? NC / 2 : (NC + 3) / 4;
   constexpr int NACC = (MODE == 2) ? 1 : 2;
   // LDS row stride in tile elements: fp64 tile nc+1 complex (odd: conflict-free 16-B reads); fp32-stored matrices keep the
   // tile as raw complex<float> with stride nc+2 (even: 16-B aligned pair stores) -- half the LDS and half the staging
   // registers, widened to fp64 only as an MFMA operand
   constexpr int RS = M32 ? NC + 2 : NC + 1;
-  constexpr int NC2 = NC * NC;
-  constexpr int NG = (NC2 + WAVE - 1) / WAVE;     // staged 16-B elements per lane per piece
+  constexpr int NG = (MEL + WAVE - 1) / WAVE;     // staged 16-B elements per lane per piece
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
   cplx* mlds = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * NC * RS;                // fp64 tile
   float2* mlds32 = reinterpret_cast<float2*>(smem_raw) + (size_t)wave * NC * RS;          // fp32 tile (M32)
   const int lr = lane & 15, lq = lane >> 4;
-  const int j = blockIdx.x * (BLOCK / WAVE) + wave;
+  const int j = (PAIR ? 2 : 1) * (blockIdx.x * (BLOCK / WAVE) + wave);   // (PAIR: the first site of the pair; the host launches it for even hr only)
   if (j >= a.hr) return;                      // whole wavefront leaves; the kernel has no block barriers
+  if constexpr (PAIR) {                       // the off-diagonal blocks of the tile: zero for the whole launch
+    for (int e = lane; e < NC * RS; e += WAVE) { if (M32) mlds32[e] = make_float2(0.0f, 0.0f); else mlds[e] = cmake(0.0, 0.0); }
+    wave_lds_handoff();
+  }
   const int kcol = (MODE == 1) ? (lr & 7) : lr;   // right-hand side this lane's MFMA column belongs to
   const bool kval = kcol < nk;                 // ... and whether it exists
   const long koff = (long)system_index(a, kcol & 15) * a.vec_stride;
@@ -1011,7 +1085,7 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
         else acc[n][t] = (v4d){0.0, 0.0, 0.0, 0.0};
       }
 
-    constexpr int NGP = M16 ? (NC2 / 4 + WAVE - 1) / WAVE : (NC2 / 2 + WAVE - 1) / WAVE;   // staged PAIRS (16-bit: QUADS) per lane per piece (narrow-stored matrices)
+    constexpr int NGP = M16 ? (MEL / 4 + WAVE - 1) / WAVE : (MEL / 2 + WAVE - 1) / WAVE;   // staged PAIRS (16-bit: QUADS) per lane per piece (narrow-stored matrices)
     // staging registers for the matrix stream (a second set, two pieces of prefetch, was measured SLOWER: 8 rhs 2.88 -> 3.10
     // ms; the registers cost a resident wavefront and the stream was not the limit -- profiles/r02_mfma_kernelC_variants.txt)
     constexpr int NGS = M32 ? NGP : NG;
@@ -1040,7 +1114,19 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
     constexpr int XROWS = (MODE == 1) ? 8 : 16;                  // right-hand sides a pass can hold (MODE 1: at most 8)
     constexpr int NXG = (XROWS * NC + WAVE - 1) / WAVE;          // staged vector elements per lane per piece
     constexpr int XPF = (VL && NXG <= 2) ? PFD : 1;               // ... and of the right-hand sides (small blocks only: nc = 8, 12)
-    cplx XG[XPF][VL ? NXG : 1];
+    // (the staged right-hand sides stay in their STORAGE form until they are parked: widening a complex<float> entry right after its load made the
+    // compiler wait for each load in turn -- load, s_waitcnt vmcnt(0), convert, next load -- BEFORE it issued the piece's matrix loads: three
+    // serial memory latencies per piece in the complex<float> forms, none of them overlapped with the MFMAs of the piece in hand)
+    typedef typename std::conditional<V32, double, cplx>::type xraw;   // V32: the raw bits of a complex<float>
+    xraw XG[XPF][VL ? NXG : 1];
+    auto ld_xraw = [](const void* base, long i) -> xraw {       // base == nullptr: a column beyond the systems of the pass (zero)
+      if constexpr (V32) return base ? reinterpret_cast<const double*>(base)[i] : 0.0;
+      else return base ? reinterpret_cast<const cplx*>(base)[i] : cmake(0.0, 0.0);
+    };
+    auto widen_xraw = [](xraw v) -> cplx {
+      if constexpr (V32) { struct F2 { float x, y; }; const F2 f = __builtin_bit_cast(F2, v); return cmake((double)f.x, (double)f.y); }
+      else return v;
+    };
     int ksys[VL ? NXG : 1];   // the system each of this lane's staged vector elements belongs to (row-invariant, no memory access: system_index)
     if constexpr (VL) {
 #pragma unroll
@@ -1054,13 +1140,13 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
     };
     auto load_matrix = [&](int pc, int gs) {      // global -> registers, lane-linear, non-temporal
       const cplx* mbase = (pc == 0) ? a.clover : a.hopping;
-      const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * NC2;
+      const long moff = ((pc == 0) ? 0 : (long)(pc - 1) * a.size_cm) + site * (SNC * SNC);   // (PAIR: the two sites' matrices are adjacent)
       if (M32) {   // pairs of complex<float> (M16: quads of complex<half>): 16 B per lane per load, kept as raw bits
 #pragma unroll
         for (int g = 0; g < NGP; g++) {
           constexpr int PER = M16 ? 4 : 2;
           const int el = PER * (g * WAVE + lane);
-          if (NC2 % (PER * WAVE) == 0 || el < NC2) {
+          if (MEL % (PER * WAVE) == 0 || el < MEL) {
             const double* pp = M16 ? reinterpret_cast<const double*>(reinterpret_cast<const unsigned*>(mbase) + moff + el)
                                    : reinterpret_cast<const double*>(reinterpret_cast<const float2*>(mbase) + moff + el);
             G[gs][g].x = __builtin_nontemporal_load(pp);
@@ -1071,7 +1157,7 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
 #pragma unroll
         for (int g = 0; g < NG; g++) {
           const int el = g * WAVE + lane;
-          G[gs][g] = (NC2 % WAVE == 0 || el < NC2) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
+          G[gs][g] = (MEL % WAVE == 0 || el < MEL) ? ldm<M32, true>(mbase, moff + el) : cmake(0.0, 0.0);
         }
       }
     };
@@ -1081,20 +1167,37 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
       const void* vbase = h_hi ? a.halo_hi : h_lo ? a.halo_lo : a.rhs;
       const long vsite = (h_hi || h_lo) ? (long)(1 - p) * a.hr + j : nb_of(pc);
       const long vstride = (h_hi || h_lo) ? a.halo_stride : a.vec_stride;
-      if constexpr (VL) {                         // lane-linear over [k][c]: element e = g*64 + lane -> (k = e / NC, c = e % NC)
+      if constexpr (VL && PAIR) {                 // [k][two sites x 8]: the second site's x-neighbour is found per lane (row-end wrap)
+        const int sp = (lane & 15) >> 3;          // (NC = 16 divides the wavefront: column = lane % 16 for every g)
+        long vs = vsite + sp;                     // own site and y-neighbours: adjacent sites
+        if (pc == 1) { int jq = j + sp + s; if (jq >= a.hr) jq -= a.hr; vs = opp + (long)y * a.hr + jq; }
+        if (pc == 3) { int jq = j + sp + s - 1; if (jq < 0) jq += a.hr; vs = opp + (long)y * a.hr + jq; }
+        const long so = vs * SNC + (lane & 7);
+#pragma unroll
+        for (int g = 0; g < NXG; g++) {
+          const int k = (g * WAVE + lane) / NC;
+          XG[xs][g] = ld_xraw((k < nk) ? vbase : nullptr, (long)ksys[g] * vstride + so);
+        }
+      } else if constexpr (VL) {                  // lane-linear over [k][c]: element e = g*64 + lane -> (k = e / NC, c = e % NC)
         const long so = vsite * NC;
 #pragma unroll
         for (int g = 0; g < NXG; g++) {
           const int e = g * WAVE + lane;
           const int k = e / NC, c = e - k * NC;
-          XG[xs][g] = (k < nk) ? ldv<V32>(vbase, (long)ksys[g] * vstride + so + c) : cmake(0.0, 0.0);
+          XG[xs][g] = ld_xraw((k < nk) ? vbase : nullptr, (long)ksys[g] * vstride + so + c);
         }
       } else {
         const long xo = (long)system_index(a, kcol & 15) * vstride + vsite * NC;    // B-operand layout straight from global memory
+        typename XRaw<V32>::type xr[KS];            // all of them requested before any is widened
 #pragma unroll
         for (int q = 0; q < KS; q++) {
           const int c = 4 * q + lq;
-          const cplx xv = (kval && c < NC) ? ldv<V32>(vbase, xo + c) : cmake(0.0, 0.0);
+          xr[q] = zero_raw<V32>();
+          if (kval && c < NC) xr[q] = ldv_raw<V32>(vbase, xo + c);
+        }
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+          const cplx xv = widen_raw<V32>(xr[q]);
           if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
           else B[set][q] = xv;
         }
@@ -1107,24 +1210,27 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
         for (int g = 0; g < NGP; g++) {
           constexpr int PER = M16 ? 4 : 2;
           const int el = PER * (g * WAVE + lane);
-          if (NC2 % (PER * WAVE) == 0 || el < NC2) {
+          if (MEL % (PER * WAVE) == 0 || el < MEL) {
+            // tile position of stored element el: row-major nc x nc -- PAIR: site sp = el / 64 owns the diagonal block (sp, sp)
+            const int trow = PAIR ? (el >> 6) * SNC + ((el & 63) >> 3) : el / NC, tcol = PAIR ? (el >> 6) * SNC + (el & 7) : el % NC;
             if constexpr (M16) {   // (re, im) x 4 halves -> two 16-B stores of complex<float> pairs (RS even, el % 4 == 0: aligned, same row)
               typedef _Float16 h8 __attribute__((ext_vector_type(8)));
               typedef float f4 __attribute__((ext_vector_type(4)));
               const h8 hv = __builtin_bit_cast(h8, G[gs][g]);
               const f4 w0 = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}, w1 = {(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
-              float2* dst = mlds32 + (el / NC) * RS + (el % NC);
+              float2* dst = mlds32 + trow * RS + tcol;
               *reinterpret_cast<f4*>(dst) = w0;
               *reinterpret_cast<f4*>(dst + 2) = w1;
             } else
-              *reinterpret_cast<cplx*>(mlds32 + (el / NC) * RS + (el % NC)) = G[gs][g];   // 16-B aligned: RS, el even
+              *reinterpret_cast<cplx*>(mlds32 + trow * RS + tcol) = G[gs][g];   // 16-B aligned: RS, el even
           }
         }
       } else {
 #pragma unroll
         for (int g = 0; g < NG; g++) {
           const int el = g * WAVE + lane;
-          if (NC2 % WAVE == 0 || el < NC2) mlds[(el / NC) * RS + (el % NC)] = G[gs][g];
+          const int trow = PAIR ? (el >> 6) * SNC + ((el & 63) >> 3) : el / NC, tcol = PAIR ? (el >> 6) * SNC + (el & 7) : el % NC;
+          if (MEL % WAVE == 0 || el < MEL) mlds[trow * RS + tcol] = G[gs][g];
         }
       }
       if constexpr (VL) {                         // the right-hand sides of the same piece, rows padded
@@ -1132,7 +1238,7 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
         for (int g = 0; g < NXG; g++) {
           const int e = g * WAVE + lane;
           const int k = e / NC, c = e - k * NC;
-          if (k < XROWS) xlds[k * XS + c] = XG[xs][g];
+          if (k < XROWS) xlds[k * XS + c] = widen_xraw(XG[xs][g]);
         }
       }
       wave_lds_handoff();
@@ -1292,9 +1398,9 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
         const int k = e / NC, r = e - k * NC;
         if (k < nk) {
           cplx v = xlds[k * XS + r];
-          const long o = (long)ksys[g] * a.vec_stride + site * NC + r;
+          const long o = (long)ksys[g] * a.vec_stride + site * SNC + r;   // (PAIR: the second site's vector follows the first's)
           if (do_shift) {
-            const double dg = (NC % 2 == 0) ? ((r < NC / 2) ? 1.0 : -1.0) : 0.0;
+            const double dg = (SNC % 2 == 0) ? (((PAIR ? (r & (SNC - 1)) : r) < SNC / 2) ? 1.0 : -1.0) : 0.0;
             const cplx sh = cmake(a.shift[0] + sg * a.eo_shift[0] + dg * a.dof_shift[0], a.shift[1] + sg * a.eo_shift[1] + dg * a.dof_shift[1]);
             cmac(v, sh, ldv<V32>(a.rhs, o));
           }
@@ -1340,6 +1446,7 @@ static int g_stencil_pair = 2;    // tuning knob: 0 = one site per lane group (k
 static int g_pair_prefetch = 1;   // tuning knob: 1 = kernel A2 prefetches the next system's right-hand side in fp64 batches
 static int g_stencil_rows = 0;   // tuning knob: cap on gridDim.y (0 = one block row per lattice row)
 static int g_stencil_mfma = 1;   // tuning knob: 1 = multi-rhs applies with nc in {8,12,16,24,32} run on the f64 matrix cores (kernel C); 2 = same, plain 4-MFMA products; 0 = off
+static int g_mfma_pair8 = 1;     // tuning knob: 1 = kernel C at nc = 8 with up to 8 systems owns two sites per wavefront, 0 = one
 static int g_mfma_vl = 1;        // tuning knob: 1 = kernel C loads / stores the right-hand sides coalesced through an LDS slice, 0 = operand-layout global accesses
 static int g_gen32 = 1;          // tuning knob: fp32-stored matrices, even nc: 1 = kernel B32 (fp32 tile end to end), 2 = same with 2-site tiles, 0 = kernel B with widening loads
 static int g_gen_sites = 0;      // tuning knob: cap on sites per block in kernel B (0 = register-limited maximum)
@@ -1389,6 +1496,7 @@ extern "C" int qmg_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gen32")) { g_gen32 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "stencil_mfma")) { g_stencil_mfma = value; return QMG_SUCCESS; }
   if (!strcmp(key, "mfma_vl")) { g_mfma_vl = value; return QMG_SUCCESS; }
+  if (!strcmp(key, "mfma_pair8")) { g_mfma_pair8 = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_tile")) { g_xfer_tile = value; return QMG_SUCCESS; }
   if (!strcmp(key, "xfer_pack")) { g_xfer_pack = value; return QMG_SUCCESS; }
   if (!strcmp(key, "wilson_pair")) { g_wilson_pair = value; return QMG_SUCCESS; }
@@ -1554,7 +1662,7 @@ __global__ void k_stencil_volume1(void* lhs_, const void* rhs_, int nc, int nrhs
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nc * nrhs) return;
   const int k = i / nc, c = i - k * nc;
-  const long o = (long)(a.use_idx ? (int)a.ridx[k] : k) * stride + c;
+  const long o = (long)system_index(a, k) * stride + c;
   ct* lhs = reinterpret_cast<ct*>(lhs_);
   const ct* rhs = reinterpret_cast<const ct*>(rhs_);
   cplx v = cmake(0.0, 0.0);
@@ -1789,6 +1897,19 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
         else if (a.vec32) QMG_MFMA_LAUNCH1(NC, MODE, true, true) else if (a.mat32) QMG_MFMA_LAUNCH1(NC, MODE, true, false) else QMG_MFMA_LAUNCH1(NC, MODE, false, false) }
 #define QMG_MFMA_LAUNCH(NC)                                                                                     \
       if (mode == 2) QMG_MFMA_LAUNCH0(NC, 2, false, false, true) else if (mode == 0) QMG_MFMA_LAUNCH2(NC, 0) else QMG_MFMA_LAUNCH2(NC, 1)
+      // nc = 8, up to 8 systems, whole lattice: two sites per wavefront (PAIR; "mfma_pair8" = 0 keeps one)
+      if (nc == 8 && mode == 1 && g_mfma_pair8 && !slab && (a.hr % 2 == 0)) {
+        const unsigned gxp = (unsigned)((a.hr / 2 + BLOCK / WAVE - 1) / (BLOCK / WAVE));
+        dim3 gridp(gxp, gy);
+        const size_t smemp = (a.mat32 ? sizeof(float2) * (size_t)(BLOCK / WAVE) * 16 * 18 : sizeof(cplx) * (size_t)(BLOCK / WAVE) * 16 * 17) +
+                             sizeof(cplx) * (size_t)(BLOCK / WAVE) * 8 * 17;
+        if (a.mat16) { if (a.vec32) k_stencil_mfma<16, 1, true, true, true, true, true><<<gridp, block, smemp, st>>>(b, nk);
+                       else k_stencil_mfma<16, 1, true, false, true, true, true><<<gridp, block, smemp, st>>>(b, nk); }
+        else if (a.vec32) k_stencil_mfma<16, 1, true, true, true, false, true><<<gridp, block, smemp, st>>>(b, nk);
+        else if (a.mat32) k_stencil_mfma<16, 1, true, false, true, false, true><<<gridp, block, smemp, st>>>(b, nk);
+        else k_stencil_mfma<16, 1, false, false, true, false, true><<<gridp, block, smemp, st>>>(b, nk);
+        continue;
+      }
       switch (nc) {
         case 8: QMG_MFMA_LAUNCH(8) break;
         case 12: QMG_MFMA_LAUNCH(12) break;

@@ -104,13 +104,21 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nul
           const long base = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc / W;
           for (int el = l; el < G; el += TPG) {
             const long kp = base + el;
+            // every load of the element first, in the storage form (qmg_common.h: a widening or a branch per load serialises them)
+            const typename RawP<T, W>::type fr = ld_rawp<T, W>(fine, kp);
+            typename RawP<T, W>::type vr[XFER_DC];
+#pragma unroll
+            for (int q = 0; q < XFER_DC; q++) {
+              vr[q] = zero_rawp<T, W>();
+              if (q < dn) vr[q] = ld_rawp_nt<T, W>(nullv, (long)(d0 + q) * (g.fsize / W) + kp);   // read-once stream: non-temporal
+            }
             cplx f[W];
-            ldc_pack<T, W>(fine, kp, f);
+            widen_rawp<T, W>(fr, f);
 #pragma unroll
             for (int q = 0; q < XFER_DC; q++)
               if (q < dn) {
                 cplx v[W];
-                ldc_pack_nt<T, W>(nullv, (long)(d0 + q) * (g.fsize / W) + kp, v);   // read-once stream: non-temporal
+                widen_rawp<T, W>(vr[q], v);
 #pragma unroll
                 for (int w = 0; w < W; w++) cmac_conj(acc[q], v[w], f[w]);
               }
@@ -301,13 +309,21 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_tile(const void* __restrict
         const int rr = t / G, el = t - rr * G;
         const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
         const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc + el;
+        typename RawC<T>::type fraw[KB], nraw[DC];   // every load of the element first, in the storage form
+#pragma unroll
+        for (int q = 0; q < KB; q++) fraw[q] = ld_raw<T>(fine, fo[q] + e);
+#pragma unroll
+        for (int dq = 0; dq < DC; dq++) {
+          nraw[dq] = zero_rawc<T>();
+          if (dq < dn) nraw[dq] = ld_raw_nt<T>(nullv, (long)(d0 + dq) * g.fsize + e);
+        }
         cplx f[KB];
 #pragma unroll
-        for (int q = 0; q < KB; q++) f[q] = ldc<T>(fine, fo[q] + e);
+        for (int q = 0; q < KB; q++) f[q] = widen_rawc<T>(fraw[q]);
 #pragma unroll
         for (int dq = 0; dq < DC; dq++) {
           if (dq < dn) {
-            const cplx nv = ldc_nt<T>(nullv, (long)(d0 + dq) * g.fsize + e);
+            const cplx nv = widen_rawc<T>(nraw[dq]);
 #pragma unroll
             for (int q = 0; q < KB; q++) {   // += conj(nv) f
               double& ar = v[(dq * KB + q) * 2];
@@ -438,28 +454,21 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_small(const void* __restric
     const int rr = have ? l / G : 0, el = have ? l - rr * G : 0;
     const int p = rr / g.by, y = cy * g.by + (rr - p * g.by);
     const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx * (g.bx / 2)) * g.fnc + el;
-    // ---- phase 1: every load of this site
-    ct fr[KB], nr[NVT];
-    ct zero;
-    zero.x = 0; zero.y = 0;
+    // ---- phase 1: every load of this site.  UNCONDITIONAL loads from addresses that are always valid (a lane without an element reads the block's
+    // first one, a null vector beyond nvec is read as vector 0, an unused system slot aliases slot 0) and are zeroed when they are used: a
+    // divergent branch around each load made the compiler close the load with a full s_waitcnt at every join (21 of 48 loads waited for alone).
+    const long e_safe = e;   // (rr = el = 0 for a lane without an element: the block's first element)
+    ct fr[KB];
+    typename RawC<T>::type nraw[NVT];   // (complex<float>: the raw 8 bytes -- splitting them behind each load made the loads wait for one another)
 #pragma unroll
-    for (int q = 0; q < KB; q++) {   // (an explicit branch: `cond ? load : zero` on a struct becomes a select of ADDRESSES and a flat load from scratch)
-      fr[q] = zero;
-      if (have && q < ns) fr[q] = reinterpret_cast<const ct*>(fine)[(long)ids.id[q] * fstride + e];
-    }
+    for (int q = 0; q < KB; q++) fr[q] = reinterpret_cast<const ct*>(fine)[(long)ids.id[q] * fstride + e_safe];
 #pragma unroll
-    for (int d = 0; d < NVT; d++) {
-      if (have && d < nvec) {
-        if (sizeof(T) == 8) {
-          const ct* src = reinterpret_cast<const ct*>(nullv) + (long)d * g.fsize + e;
-          nr[d].x = __builtin_nontemporal_load(&src->x);
-          nr[d].y = __builtin_nontemporal_load(&src->y);
-        } else {   // ONE 8-byte load (two component loads would be two 4-byte instructions)
-          const long long raw = __builtin_nontemporal_load(reinterpret_cast<const long long*>(nullv) + (long)d * g.fsize + e);
-          nr[d].x = (T)__int_as_float((int)(raw & 0xFFFFFFFFll));
-          nr[d].y = (T)__int_as_float((int)(raw >> 32));
-        }
-      } else nr[d] = zero;
+    for (int d = 0; d < NVT; d++) nraw[d] = ld_raw_nt<T>(nullv, (long)(d < nvec ? d : 0) * g.fsize + e_safe);   // (complex<float>: ONE 8-byte load)
+    {
+      ct zero;
+      zero.x = 0; zero.y = 0;
+#pragma unroll
+      for (int q = 0; q < KB; q++) if (!(have && q < ns)) fr[q] = zero;
     }
     // ---- phase 2: products and recursive halving, out of registers
     double res[NP];
@@ -468,7 +477,9 @@ __global__ __launch_bounds__(BLOCK) void k_brestrict_small(const void* __restric
       double v[NV];
 #pragma unroll
       for (int dq = 0; dq < DC; dq++) {
-        const double nx = (double)nr[ps * DC + dq].x, ny = (double)nr[ps * DC + dq].y;
+        const cplx nw = widen_rawc<T>(nraw[ps * DC + dq]);
+        const bool nval = have && (ps * DC + dq) < nvec;
+        const double nx = nval ? nw.x : 0.0, ny = nval ? nw.y : 0.0;
 #pragma unroll
         for (int q = 0; q < KB; q++) {   // conj(nv) f
           const double fx = (double)fr[q].x, fy = (double)fr[q].y;

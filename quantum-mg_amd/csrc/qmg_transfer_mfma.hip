@@ -26,9 +26,9 @@
 
 namespace qmg {
 
-// tuning knob "xfer_mfma": 1 (default) = the matrix cores where they are the faster kernel -- the complex<float> restrict (2048^2 -> 512^2 x 24, 8 systems:
-// 1.49 -> 1.10 ms; 512^2 -> 128^2: 1.10 -> 0.59 ms; 4096^2 -> 1024^2 x 8: 2.77 -> 2.21 ms; profiles/r03_xfer_mfma.txt), where the vector-FMA kernel is
-// bound by its cross-lane sums; the fp64 restrict and both prolongs stay with the vector-FMA kernels, which are at or above the MFMA form there;
+// tuning knob "xfer_mfma": 1 (default) = the matrix cores where they are the faster kernel -- the complex<float> restrict from the fine level with 5-8
+// systems (restrict_batch_mfma below: the list shrank when the vector-FMA restricts were fixed); the fp64 restrict and both prolongs stay with the
+// vector-FMA kernels, which are at or above the MFMA form there;
 // 2 = every shape the MFMA kernels serve (measurements); 0 = never
 int g_xfer_mfma = 1;
 
@@ -329,8 +329,11 @@ static int prolong_mfma_t(const void* nullvecs, int nvec, const void* coarse, vo
 int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fine, void* coarse, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
                         long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st) {
   if (!g_xfer_mfma || (g_xfer_mfma == 1 && !f32)) return SITE_DECLINED;
-  // half-filled MFMA columns on the thinnest contraction (4096^2 nc 2 -> 1024^2 x 8 with <= 4 systems: 1.89 ms against the vector kernel's 1.36)
-  if (g_xfer_mfma == 1 && n <= 4 && nvec <= 8 && fnc <= 2) return SITE_DECLINED;
+  // auto: where the matrix-core form is still the faster one AFTER the vector-FMA restricts stopped waiting for their loads one by one (qmg_common.h,
+  // RawC): complex<float>, 5-8 systems, from the nc = 2 fine level to >= 16 null vectors (2048^2 -> 512^2 x 24: 1.09 against 1.33 ms).  Elsewhere
+  // the vector kernels are equal or better now (512^2 -> 128^2 x 24, 8 systems: 0.55 against 0.58 ms; 1024^2 -> 256^2 x 8: 0.29 against 0.34;
+  // every shape at <= 4 systems: 0.17-0.72 against 0.33-1.03 ms; profiles/r03_xfer_mfma.txt).
+  if (g_xfer_mfma == 1 && !(n >= 5 && fnc <= 2 && nvec >= 16)) return SITE_DECLINED;
   XferGeomM g = {fhr, fLy, fnc, chr, cLy, cnc, bx, by, fhalf_vol, fsize};
   PassIdsM ids;
   ids.n = n;

@@ -47,6 +47,12 @@ struct VecPool {
     for (auto it = sh.free_by_cap.lower_bound(n); it != sh.free_by_cap.end() && it->first <= 2 * n; ++it)
       if (!it->second.empty()) { p = it->second.back(); it->second.pop_back(); sh.cached_elems -= it->first; break; }
     if (!p) {
+      // nothing cached serves the request.  If the HBM that is left cannot either, the cached blocks of OTHER capacities are given back first (a
+      // batch of 3 systems after single-system solves found 36 GB of single-system scratch on the free list that no request of its own could
+      // take, and ran out of memory at basis vector 56 of 128: batch_systems_that_fit counts cached scratch as free, so it has to be)
+      size_t free_b = 0, total_b = 0;
+      const size_t need = n * sizeof(complex<double>);
+      if (sh.cached_elems > 0 && qmg_mem_info(&free_b, &total_b) == QMG_SUCCESS && free_b < need + ((size_t)1 << 30)) release_all();
       p = allocate_vector<complex<double>>(n);
       if (p) sh.cap[p] = n;
     }
