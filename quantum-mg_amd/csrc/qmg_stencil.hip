@@ -1187,17 +1187,20 @@ __global__ __launch_bounds__(BLOCK, (QMG_KC_F32_PF2 && MODE == 1 && M32 && V32 &
           XG[xs][g] = ld_xraw((k < nk) ? vbase : nullptr, (long)ksys[g] * vstride + so + c);
         }
       } else {
-        const long xo = (long)system_index(a, kcol & 15) * vstride + vsite * NC;    // B-operand layout straight from global memory
+        const long xo = (long)system_index(a, kval ? (kcol & 15) : 0) * vstride + vsite * NC;    // B-operand layout straight from global memory (a column beyond the pass: system 0's address, value zeroed)
         typename XRaw<V32>::type xr[KS];            // all of them requested before any is widened
+        // (unconditional: a lane whose column is beyond the pass reads the pass's first system, a k-step beyond nc reads entry 0; both are zeroed
+        // below.  A divergent branch around each load closed it with a full wait.)
 #pragma unroll
         for (int q = 0; q < KS; q++) {
           const int c = 4 * q + lq;
-          xr[q] = zero_raw<V32>();
-          if (kval && c < NC) xr[q] = ldv_raw<V32>(vbase, xo + c);
+          xr[q] = ldv_raw<V32>(vbase, xo + ((NC % 4 == 0 || c < NC) ? c : 0));
         }
 #pragma unroll
         for (int q = 0; q < KS; q++) {
-          const cplx xv = widen_raw<V32>(xr[q]);
+          const int c = 4 * q + lq;
+          const cplx xw = widen_raw<V32>(xr[q]);
+          const cplx xv = (kval && (NC % 4 == 0 || c < NC)) ? xw : cmake(0.0, 0.0);
           if constexpr (MODE == 1) B[set][q] = (lr < 8) ? xv.x : xv.y;
           else B[set][q] = xv;
         }

@@ -231,9 +231,14 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
       const long e = ((long)p * g.fhalf_vol + (long)y * g.fhr + (long)cx0 * (g.bx / 2)) * g.fnc + u;
       const lt* cs = cl + s * sstride;
       auto wide = [](const lt v) { return cmake((double)v.x, (double)v.y); };
+      // the fine values this element is added to: requested now, in the storage form, widened and added after the products (an accumulator that
+      // STARTS from the widened load makes the first multiply-add wait for it, and the widenings behind the loads made them wait for one another)
+      typename RawC<T>::type fraw[KB];
+#pragma unroll
+      for (int q = 0; q < KB; q++) fraw[q] = ld_raw<T>(fine, fo[q] + e);
       cplx acc[KB];
 #pragma unroll
-      for (int q = 0; q < KB; q++) acc[q] = ldc<T>(fine, fo[q] + e);
+      for (int q = 0; q < KB; q++) acc[q] = cmake(0.0, 0.0);
       int d = 0;
       // NVB null-vector entries requested together and kept in their STORAGE type until they are used: a thread has NVB x 8 (complex<float>) or
       // NVB x 16 bytes in flight; with 4 of them the complex<float> form had 32 B per thread outstanding and ran at 0.42-0.48 of the HBM rate
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_bprolong_tile(const void* __restrict_
       }
 #pragma unroll
       for (int q = 0; q < KB; q++)
-        if (q < ns) stc<T>(fine, fo[q] + e, acc[q]);
+        if (q < ns) stc<T>(fine, fo[q] + e, cadd(widen_rawc<T>(fraw[q]), acc[q]));
     }
   }
 }
