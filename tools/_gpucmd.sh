@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_f32.py tests/test_gpu_parity.py tests/test_gpu_batch.py tests/test_gpu_kcycle.py -m gpu -x -q > gpurun_out/r3_t33.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r3_t33.log
-python tools/xfer_bench.py > gpurun_out/r3_xfer8.txt 2>&1; grep "mfma=1" gpurun_out/r3_xfer8.txt | grep "prolong" | grep "k=8"
-python tools/kernelc_bench.py 24 8 > gpurun_out/r3_kc_raw3.txt 2>&1; grep "k=16" gpurun_out/r3_kc_raw3.txt | grep -v "mat16"
+timeout -k 10 1000 python -m pytest tests/test_gpu_slab.py tests/test_gpu_kcycle.py -m gpu -x -q > gpurun_out/r3_t34.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r3_t34.log
+cd quantum-mg_amd/drivers
+for i in 1 2; do env QMG_QUIET=1 ./slab_wilson_solve 4096 0.05 6.0 200 1337 1e-10 1 1 2>&1 | grep -E "BiCGStab" ; done
