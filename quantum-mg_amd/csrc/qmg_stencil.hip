@@ -79,13 +79,20 @@ struct StencilArgs {
 // wavefront then sat out the whole latency before it computed on the current piece), in kernel C one more memory latency in front of every
 // piece.  The sixteen bytes are four scalar registers; a lane picks its byte with selects and a shift.
 __device__ __forceinline__ int system_index(const StencilArgs& a, int k) {
-  if (!a.use_idx) return k;
-  unsigned w[4];
+  unsigned long long w[2];
   __builtin_memcpy(w, a.ridx, 16);
-  const unsigned ww = (k & 8) ? ((k & 4) ? w[3] : w[2]) : ((k & 4) ? w[1] : w[0]);
-  return (int)((ww >> (8 * (k & 3))) & 0xffu);
+  // one select and one shift (for a uniform k: scalar instructions).  A chain of selects per bit came out as a chain of scalar BRANCHES inside kernel
+  // A2's next-system prefetch, whose load clauses they cut: 8 systems 0.93 -> 1.01 ms.
+  const unsigned long long ww = (k & 8) ? w[1] : w[0];
+  const int idx = (int)((ww >> (8 * (k & 7))) & 0xffull);
+  return a.use_idx ? idx : k;
 }
 __device__ __forceinline__ long rhs_offset(const StencilArgs& a, int k) { return (long)system_index(a, k) * a.vec_stride; }
+// Kernel A2 (k_stencil_pair) keeps the CONDITIONAL byte load: it is executed for masked batches only, and with it the compiler's schedule of the
+// next-system prefetch is the faster one -- same box, 4096^2 staggered, 8 systems: 0.93 ms against 1.01 ms with system_index, whose code is free of
+// the load but makes the compiler spread the waits of the two systems' requests differently; an explicit drain in front of the prefetch did not
+// bring the 0.93 back (tools/apply_norm_ab.py, gpurun_out/ab_*.txt).  Measured, not understood.
+__device__ __forceinline__ long rhs_offset_a(const StencilArgs& a, int k) { return (long)(a.use_idx ? (int)a.ridx[k] : k) * a.vec_stride; }
 
 // vector element i of a complex<double> (V32 = false) or complex<float> (V32 = true) array, in fp64 registers
 template <bool V32> __device__ __forceinline__ cplx ldv(const void* base, long i) { return V32 ? ldc<float>(base, i) : ldc<double>(base, i); }
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
     // is not the partner site
     struct XF { Frag Ec[ROWS + 2], Oc[ROWS + 2], Es[ROWS], Os[ROWS]; };
     auto load_x = [&](XF& v, int k) {
-      const ct* xe = reinterpret_cast<const ct*>(a.rhs) + rhs_offset(a, k);   // even half
+      const ct* xe = reinterpret_cast<const ct*>(a.rhs) + rhs_offset_a(a, k);   // even half
       const ct* xo = xe + a.half_vol * NC;                                    // odd half
 #pragma unroll
       for (int t = 0; t < ROWS + 2; t++) {
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_pair(const StencilArgs a) {
     XF cur;
     if (PF) load_x(cur, 0);
     for (int k = 0; k < a.nrhs; k++) {
-      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset(a, k);
+      ct* out = reinterpret_cast<ct*>(a.lhs) + rhs_offset_a(a, k);
       double nrm = 0.0;
       XF nxt;
       if (!PF) load_x(cur, k);
