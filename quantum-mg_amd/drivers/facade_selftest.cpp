@@ -249,6 +249,60 @@ int main(int argc, char** argv) {
     delete[] nv;
   }
 
+  // ---- the batch engine's operators by type (include/qmg/batch.hpp: apply_stencil_typed_batch / prepare_M_batch / reconstruct_M_batch) against the
+  // single-vector type dispatch (Stencil2D::apply_M / prepare_M / reconstruct_M, stencil_2d.h:2418-2527): all nine types, three systems, on the Wilson
+  // operator (nc = 2 kernels) and on a Galerkin operator with every variant built (nc = 8 kernels)
+  {
+    const int nvec = 8, nb = 3;
+    Lattice2D latc(L / 4, L / 4, nvec);
+    complex<double>** nv = new complex<double>*[nvec];
+    for (int j = 0; j < nvec; j++) { nv[j] = allocate_vector<complex<double>>(n2); gaussian(nv[j], n2, 900ull + j); }
+    TransferMG tr(&lat2, &latc, nv, true, false, QMG_DOUBLE_NONE);
+    CoarseOperator2D co(&latc, &wilson, &lat2, &tr, false, false, CoarseOperator2D::QMG_COARSE_BUILD_ALL);
+    co.disable_f32_matrices();
+    const QMGStencilType types[9] = {QMG_MATVEC_ORIGINAL, QMG_MATVEC_DAGGER, QMG_MATVEC_RIGHT_JACOBI, QMG_MATVEC_RIGHT_SCHUR, QMG_MATVEC_M_MDAGGER,
+                                     QMG_MATVEC_MDAGGER_M, QMG_MATVEC_RBJ_DAGGER, QMG_MATVEC_RBJ_M_MDAGGER, QMG_MATVEC_RBJ_MDAGGER_M};
+    Stencil2D* ops[2] = {&wilson, &co};
+    for (int o = 0; o < 2; o++) {
+      Stencil2D* st = ops[o];
+      const size_t n = (size_t)st->get_lattice()->get_size_cv_l();
+      qmg::BatchPool pool(n, nb);
+      qmg::Batch in = pool.get(), rhs2 = pool.get(), out = pool.get(), ref = pool.get();
+      const unsigned all = qmg::full_mask(nb);
+      for (int k = 0; k < nb; k++) { gaussian(in.vec(k), (long)n, 950ull + 10 * o + k); gaussian(rhs2.vec(k), (long)n, 980ull + 10 * o + k); }
+      double worst_apply = 0.0, worst_prep = 0.0, worst_rec = 0.0;
+      for (int t = 0; t < 9; t++) {
+        const size_t nsolve = (types[t] == QMG_MATVEC_RIGHT_SCHUR) ? n / 2 : n;
+        BatchOp bop(st, types[t]);
+        qmg::bzero(out, n, all); qmg::bzero(ref, n, all);
+        apply_stencil_typed_batch<double>(out, in, all, (void*)&bop);
+        for (int k = 0; k < nb; k++) Stencil2D::get_apply_function(types[t])(ref.vec(k), in.vec(k), (void*)st);
+        for (int k = 0; k < nb; k++) worst_apply = std::max(worst_apply, sqrt(diffnorm2sq(out.vec(k), ref.vec(k), (long)nsolve) / norm2sq(ref.vec(k), (long)nsolve)));
+        qmg::bzero(out, n, all); qmg::bzero(ref, n, all);
+        prepare_M_batch<double>(st, types[t], out, in, all);
+        for (int k = 0; k < nb; k++) st->prepare_M(ref.vec(k), in.vec(k), types[t]);
+        for (int k = 0; k < nb; k++) worst_prep = std::max(worst_prep, sqrt(diffnorm2sq(out.vec(k), ref.vec(k), (long)n) / norm2sq(ref.vec(k), (long)n)));
+        qmg::bzero(out, n, all); qmg::bzero(ref, n, all);
+        reconstruct_M_batch<double>(st, types[t], out, in, rhs2, all);
+        for (int k = 0; k < nb; k++) st->reconstruct_M(ref.vec(k), in.vec(k), rhs2.vec(k), types[t]);
+        for (int k = 0; k < nb; k++) worst_rec = std::max(worst_rec, sqrt(diffnorm2sq(out.vec(k), ref.vec(k), (long)n) / norm2sq(ref.vec(k), (long)n)));
+      }
+      check(worst_apply < 1e-13, o == 0 ? "batch applies by type == Stencil2D::apply_M by type (Wilson, 9 types x 3 systems)" : "batch applies by type == apply_M by type (Galerkin nc = 8, 9 types x 3 systems)", worst_apply);
+      check(worst_prep < 1e-13, o == 0 ? "prepare_M_batch == prepare_M (Wilson)" : "prepare_M_batch == prepare_M (Galerkin nc = 8)", worst_prep);
+      check(worst_rec < 1e-13, o == 0 ? "reconstruct_M_batch == reconstruct_M (Wilson)" : "reconstruct_M_batch == reconstruct_M (Galerkin nc = 8)", worst_rec);
+      // a normal operator with CoarsestSolveMG::normal_shift (shift_function, stateful_multigrid.h:724-729)
+      BatchOp sh(st, QMG_MATVEC_RBJ_MDAGGER_M);
+      sh.normal_shift = complex<double>(0.37, 0.0); sh.shift_length = n;
+      apply_stencil_typed_batch<double>(out, in, all, (void*)&sh);
+      Stencil2D::get_apply_function(QMG_MATVEC_RBJ_MDAGGER_M)(ref.vec(1), in.vec(1), (void*)st);
+      caxpy(complex<double>(0.37, 0.0), in.vec(1), ref.vec(1), (long)n);
+      const double dsh = sqrt(diffnorm2sq(out.vec(1), ref.vec(1), (long)n) / norm2sq(ref.vec(1), (long)n));
+      check(dsh < 1e-13, o == 0 ? "shifted normal operator (Wilson)" : "shifted normal operator (Galerkin nc = 8)", dsh);
+    }
+    for (int j = 0; j < nvec; j++) deallocate_vector(&nv[j]);
+    delete[] nv;
+  }
+
   // ---- clear_stencils / prune_stencils on an operator that applies straight from the links: the cached link copy must
   // not outlive the stored arrays.  Reference semantics (stencil_2d.h:339-404): after clear_stencils the matrices are zero, so
   // apply_M adds shift * rhs and nothing else; after pruning the hopping term only clover + shift act.

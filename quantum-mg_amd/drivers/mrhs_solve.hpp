@@ -29,7 +29,8 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
   const size_t n = (size_t)lat0->get_size_cv_l();
   {
     BatchKcycle probe(mg, 1);
-    if (!probe.supported() || !BatchOp::supported(solve_type)) { std::cout << "[QMG-ERROR]: the batched K-cycle implements the ORIGINAL and RIGHT_SCHUR configurations only.\n"; return false; }
+    if (solve_type != QMG_MATVEC_ORIGINAL && solve_type != QMG_MATVEC_RIGHT_SCHUR) { std::cout << "[QMG-ERROR]: this driver's outer solve is on the ORIGINAL or the RIGHT_SCHUR operator.\n"; return false; }
+    if (!probe.supported()) { std::cout << "[QMG-ERROR]: the batched K-cycle does not implement this hierarchy's level / coarsest operator types (or a variant stencil they name is not built).\n"; return false; }
   }
   if (getenv("QMG_F32_KCYCLE")) f32_kcycle = true;
   if (f32_kcycle) {

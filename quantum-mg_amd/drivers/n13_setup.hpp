@@ -165,10 +165,15 @@ inline int N13::build(int argc, char** argv) {
   qmg_driver::phase("setup: fine operator", root);
   auto t_setup0 = std::chrono::steady_clock::now();
   wilson_op = new Wilson2D(lats[0], mass, gauge_field);
-  if (cgne) wilson_op->build_dagger_stencil();
+  // QMG_COARSEST_TYPE=mmd | mdm (test hook): the coarsest solve by CG on M M^dagger / M^dagger M (stateful_multigrid.h:930-960); QMG_NORMAL_SHIFT=s adds s to it
+  const std::string coarsest_env = getenv("QMG_COARSEST_TYPE") ? getenv("QMG_COARSEST_TYPE") : "";
+  const QMGStencilType coarsest_type = (coarsest_env == "mmd") ? QMG_MATVEC_M_MDAGGER : (coarsest_env == "mdm") ? QMG_MATVEC_MDAGGER_M : QMG_MATVEC_ORIGINAL;
+  const bool want_dagger = cgne || coarsest_type != QMG_MATVEC_ORIGINAL;
+  if (want_dagger) wilson_op->build_dagger_stencil();
   level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
   coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
-  coarsest_solve_obj->coarsest_stencil_app = QMG_MATVEC_ORIGINAL;
+  coarsest_solve_obj->coarsest_stencil_app = coarsest_type;
+  if (getenv("QMG_NORMAL_SHIFT")) coarsest_solve_obj->normal_shift = atof(getenv("QMG_NORMAL_SHIFT"));
   coarsest_solve_obj->coarsest_tol = coarsest_tol;
   coarsest_solve_obj->coarsest_iters = coarsest_max_iter;
   coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
@@ -241,7 +246,7 @@ inline int N13::build(int argc, char** argv) {
     level_solve_objs[i - 1]->post_iters = n_post_smooth;
     level_solve_objs[i - 1]->pre_cgne = level_solve_objs[i - 1]->post_cgne = cgne;
     mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, true, MultigridMG::QMG_MULTIGRID_PRECOND_ORIGINAL,
-                          cgne ? CoarseOperator2D::QMG_COARSE_BUILD_DAGGER : CoarseOperator2D::QMG_COARSE_BUILD_ORIGINAL, null_vectors);
+                          want_dagger ? CoarseOperator2D::QMG_COARSE_BUILD_DAGGER : CoarseOperator2D::QMG_COARSE_BUILD_ORIGINAL, null_vectors);
     auto t3 = now();
     t_null += secs(t0, t1); t_ortho += secs(t1, t2); t_galerkin += secs(t2, t3);
     for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);

@@ -49,7 +49,16 @@ static int run(int rank, int world, int device, bool slab_mode, int argc, char**
   const int n_pre_smooth = 2; const double pre_smooth_tol = 1e-15;
   const int n_post_smooth = 2; const double post_smooth_tol = 1e-15;
   const double coarsest_tol = 0.2; const int coarsest_max_iter = 1000; const int coarsest_restart_freq = 32;
-  const QMGStencilType solve_type = QMG_MATVEC_RIGHT_SCHUR;
+  // n19:107 fixes RIGHT_SCHUR; the reference's other branches (n19:299-318) are reachable here through the environment (test hooks):
+  //   QMG_SOLVE_TYPE=jacobi       outer solve, levels and coarsest solve on the RIGHT_JACOBI operator (full vectors)
+  //   QMG_COARSEST_TYPE=rbj_mmd | rbj_mdm   coarsest solve by CG on M_rbj M_rbj^dagger / M_rbj^dagger M_rbj ; QMG_NORMAL_SHIFT=s adds s to it
+  //   QMG_SMOOTHER=cgne           CGNE smoothers (act on RIGHT_JACOBI levels; the reference ignores the flag on Schur levels)
+  const string solve_env = getenv("QMG_SOLVE_TYPE") ? getenv("QMG_SOLVE_TYPE") : "schur";
+  const string coarsest_env = getenv("QMG_COARSEST_TYPE") ? getenv("QMG_COARSEST_TYPE") : "";
+  const bool cgne = getenv("QMG_SMOOTHER") && string(getenv("QMG_SMOOTHER")) == "cgne";
+  const QMGStencilType solve_type = (solve_env == "jacobi") ? QMG_MATVEC_RIGHT_JACOBI : QMG_MATVEC_RIGHT_SCHUR;
+  const QMGStencilType coarsest_type = (coarsest_env == "rbj_mmd") ? QMG_MATVEC_RBJ_M_MDAGGER : (coarsest_env == "rbj_mdm") ? QMG_MATVEC_RBJ_MDAGGER_M : solve_type;
+  const bool want_rbj_dagger = cgne || coarsest_type != solve_type;
   unsigned long long seed = 1337ull;
 
   inversion_info invif;
@@ -78,10 +87,12 @@ static int run(int rank, int world, int device, bool slab_mode, int argc, char**
 
   Wilson2D* wilson_op = new Wilson2D(lats[0], mass, gauge_field);
   wilson_op->build_rbjacobi_stencil();   // n19:155
+  if (want_rbj_dagger) wilson_op->build_rbj_dagger_stencil();
 
   StatefulMultigridMG::LevelSolveMG** level_solve_objs = new StatefulMultigridMG::LevelSolveMG*[n_refine];
   StatefulMultigridMG::CoarsestSolveMG* coarsest_solve_obj = new StatefulMultigridMG::CoarsestSolveMG;
-  coarsest_solve_obj->coarsest_stencil_app = solve_type;
+  coarsest_solve_obj->coarsest_stencil_app = coarsest_type;
+  if (getenv("QMG_NORMAL_SHIFT")) coarsest_solve_obj->normal_shift = atof(getenv("QMG_NORMAL_SHIFT"));
   coarsest_solve_obj->coarsest_tol = coarsest_tol;
   coarsest_solve_obj->coarsest_iters = coarsest_max_iter;
   coarsest_solve_obj->coarsest_restart_freq = coarsest_restart_freq;
@@ -127,15 +138,18 @@ static int run(int rank, int world, int device, bool slab_mode, int argc, char**
     level_solve_objs[i - 1]->pre_iters = n_pre_smooth;
     level_solve_objs[i - 1]->post_tol = post_smooth_tol;
     level_solve_objs[i - 1]->post_iters = n_post_smooth;
+    level_solve_objs[i - 1]->pre_cgne = level_solve_objs[i - 1]->post_cgne = cgne;
     mg_object->push_level(lats[i], transfer_objs[i - 1], level_solve_objs[i - 1], true, Wilson2D::has_chirality() == QMG_CHIRAL_YES, stencil_to_coarsen,
-                          CoarseOperator2D::QMG_COARSE_BUILD_RBJACOBI, null_vectors);
+                          want_rbj_dagger ? CoarseOperator2D::QMG_COARSE_BUILD_RBJDAGGER : CoarseOperator2D::QMG_COARSE_BUILD_RBJACOBI, null_vectors);
     for (int j = 0; j < coarse_dof; j++) deallocate_vector(&null_vectors[j]);
     delete[] null_vectors;
     cout << "[QMG-SETUP]: level " << i << " = " << curr_x_len << "x" << curr_y_len << " nc " << coarse_dof << " built from the rbjacobi stencil\n";
   }
 
   matrix_op_cplx apply_stencil_op = Stencil2D::get_apply_function(solve_type);
-  const int solve_size = lats[0]->get_size_cv() / 2;
+  const int solve_size = (solve_type == QMG_MATVEC_RIGHT_SCHUR) ? lats[0]->get_size_cv() / 2 : lats[0]->get_size_cv();   // n19:300
+  if (solve_type != QMG_MATVEC_RIGHT_SCHUR || coarsest_type != solve_type || cgne)
+    cout << "[QMG-INFO]: solve type " << solve_env << " ; coarsest operator " << (coarsest_env.empty() ? solve_env : coarsest_env) << (cgne ? " ; CGNE smoothers" : "") << "\n";
 
   complex<double>* b = mg_object->check_out(0);
   gaussian_lattice(b, lats[0]->get_dim_mu(0), lats[0]->get_dim_mu(1), lats[0]->get_nc(), seed++);
@@ -165,6 +179,11 @@ static int run(int rank, int world, int device, bool slab_mode, int argc, char**
   mg_object->apply_stencil(Ax, x_reconstruct, 0);   // the ORIGINAL operator
   const double true_res = sqrt(diffnorm2sq(b, Ax, lats[0]->get_size_cv_l())) / bnorm;
   cout << "Check tolerance " << true_res << "\n";
+  if (!slab_mode && getenv("QMG_DUMP_DIR")) {   // test hook: the reconstructed solution as raw complex128
+    const std::vector<complex<double>> hx = qmg::to_host(x_reconstruct, (size_t)lats[0]->get_size_cv_l());
+    FILE* f = fopen((string(getenv("QMG_DUMP_DIR")) + "/x.bin").c_str(), "wb");
+    if (f) { fwrite(hx.data(), sizeof(complex<double>), hx.size(), f); fclose(f); }
+  }
   if (slab_mode) { const double xn = norm2sq(x_reconstruct, lats[0]->get_size_cv_l()); cout << setprecision(15) << "[QMG-SLAB]: world " << world << " ; |b| " << bnorm << " ; |x|^2 " << xn << "\n" << setprecision(20); }
   cout << setprecision(6) << "[QMG-TIMING]: solve " << solve_s << " s ; outer iterations/s " << invif.iter / solve_s << "\n";
   mg_object->check_in(b_prep, 0); mg_object->check_in(x_reconstruct, 0); mg_object->check_in(Ax, 0); mg_object->check_in(x, 0); mg_object->check_in(b, 0);

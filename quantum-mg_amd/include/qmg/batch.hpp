@@ -187,12 +187,28 @@ inline void apply_stencil_2D_M_batch(qmg::Batch lhs, qmg::Batch rhs, unsigned ma
   ((Stencil2D*)extra_data)->apply_M_overwrite_batch(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
 }
 
-// ---- operator variants for a batch: ORIGINAL and the right-block-Jacobi Schur complement (stencil_2d.h:1886-1983) ----
+// ---- operator variants for a batch (stencil_2d.h:2418-2566): ORIGINAL, the right-block-Jacobi operator and its Schur complement on the K-cycle's levels;
+// additionally the four normal-equation forms for the coarsest solve (CG) and the dagger forms the CGNE smoothers end with ----
 struct BatchOp {
   Stencil2D* st;
   QMGStencilType type;
-  BatchOp(Stencil2D* st_, QMGStencilType type_) : st(st_), type(type_) {}
-  static bool supported(QMGStencilType t) { return t == QMG_MATVEC_ORIGINAL || t == QMG_MATVEC_RIGHT_SCHUR; }
+  complex<double> normal_shift;   // CoarsestSolveMG::normal_shift: added to a normal operator (shift_function, stateful_multigrid.h:724-729)
+  size_t shift_length;
+  BatchOp(Stencil2D* st_, QMGStencilType type_) : st(st_), type(type_), normal_shift(0.0), shift_length(0) {}
+  // operator of a K-cycle level (smoothed with MR / CGNE, solved with flexible GCR)
+  static bool supported(QMGStencilType t) { return t == QMG_MATVEC_ORIGINAL || t == QMG_MATVEC_RIGHT_JACOBI || t == QMG_MATVEC_RIGHT_SCHUR; }
+  static bool is_normal(QMGStencilType t) { return t == QMG_MATVEC_M_MDAGGER || t == QMG_MATVEC_MDAGGER_M || t == QMG_MATVEC_RBJ_M_MDAGGER || t == QMG_MATVEC_RBJ_MDAGGER_M; }
+  // which variant stencils an operator type needs built (and, for complex<float> vectors, shadowed)
+  static bool variants_built(Stencil2D* st, QMGStencilType t) {
+    if (!st) return false;
+    switch (t) {
+      case QMG_MATVEC_ORIGINAL: return true;
+      case QMG_MATVEC_RIGHT_JACOBI: case QMG_MATVEC_RIGHT_SCHUR: return st->built_rbjacobi;
+      case QMG_MATVEC_DAGGER: case QMG_MATVEC_M_MDAGGER: case QMG_MATVEC_MDAGGER_M: return st->built_dagger;
+      case QMG_MATVEC_RBJ_DAGGER: case QMG_MATVEC_RBJ_M_MDAGGER: case QMG_MATVEC_RBJ_MDAGGER_M: return st->built_rbjacobi && st->built_rbj_dagger;
+      default: return false;
+    }
+  }
 };
 template <typename T> inline qmg::BatchT<T> batch_odd_half(qmg::BatchT<T> v, size_t half) { return qmg::BatchT<T>(v.p + half, v.stride, v.nrhs); }
 
@@ -212,21 +228,61 @@ template <typename T>
 inline void apply_M_overwrite_batch_t(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
   st->launch_set_batch<T>(QMG_P_ALL | QMG_P_ZERO, lhs.p, rhs.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, lhs.nrhs, lhs.stride, mask);
 }
-// lhs_k = M M^dagger rhs_k (apply_M_M_dagger, stencil_2d.h:1404-1416): the operator of the CGNE smoothers
+// lhs_k = (1 + H') rhs_k (apply_M_rbjacobi, stencil_2d.h:1818-1844): the identity clover as a unit shift, the identity matrices are never read
 template <typename T>
-inline void apply_M_M_dagger_batch(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+inline bool apply_M_rbjacobi_batch(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  if (!st->built_rbjacobi) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbjacobi (batch), but the rbjacobi stencil has not been allocated.\n"; return false; }
+  st->launch_set_batch<T>(QMG_P_HOPPING | QMG_P_SHIFT | QMG_P_ZERO, lhs.p, rhs.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 1.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  return true;
+}
+// lhs_k = (1 + H')^dagger rhs_k (apply_M_rbj_dagger, :2265-2278)
+template <typename T>
+inline bool apply_M_rbj_dagger_batch(Stencil2D* st, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  if (!st->built_rbj_dagger) { std::cout << "[QMG-WARNING]: Tried to call apply_M_rbj_dagger (batch), but the right jacobi dagger stencil has not been allocated.\n"; return false; }
+  if (sizeof(T) == sizeof(float) && (!st->f32.on || st->f32.rbj_dagger_hopping == 0)) {
+    std::cout << "[QMG-ERROR]: fp32 right-block-Jacobi dagger apply without its fp32 shadow (build_rbj_dagger_stencil before enable_f32_shadow).\n";
+    return false;
+  }
+  st->launch_set_batch<T>(QMG_P_HOPPING | QMG_P_SHIFT | QMG_P_ZERO, lhs.p, rhs.p, Stencil2D::QMG_ARR_RBJ_DAGGER, 1.0, 0.0, 0.0, lhs.nrhs, lhs.stride, mask);
+  return true;
+}
+// the second factor of a normal operator: lhs = F2 (F1 rhs) with F1, F2 out of {M, M^dagger, M_rbj, M_rbj^dagger}
+template <typename T>
+inline bool apply_factor_batch(Stencil2D* st, QMGStencilType factor, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  switch (factor) {
+    case QMG_MATVEC_ORIGINAL: apply_M_overwrite_batch_t<T>(st, lhs, rhs, mask); return true;
+    case QMG_MATVEC_DAGGER: return st->apply_M_dagger_overwrite_batch_t<T>(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
+    case QMG_MATVEC_RIGHT_JACOBI: return apply_M_rbjacobi_batch<T>(st, lhs, rhs, mask);
+    case QMG_MATVEC_RBJ_DAGGER: return apply_M_rbj_dagger_batch<T>(st, lhs, rhs, mask);
+    default: return false;
+  }
+}
+// a normal operator's factors, applied right to left: type = second (first rhs)
+inline void normal_factors(QMGStencilType type, QMGStencilType* first, QMGStencilType* second) {
+  switch (type) {
+    case QMG_MATVEC_M_MDAGGER: *first = QMG_MATVEC_DAGGER; *second = QMG_MATVEC_ORIGINAL; break;             // apply_M_M_dagger (:1424-1435)
+    case QMG_MATVEC_MDAGGER_M: *first = QMG_MATVEC_ORIGINAL; *second = QMG_MATVEC_DAGGER; break;             // apply_M_dagger_M (:1400-1411)
+    case QMG_MATVEC_RBJ_M_MDAGGER: *first = QMG_MATVEC_RBJ_DAGGER; *second = QMG_MATVEC_RIGHT_JACOBI; break; // apply_M_rbjacobi_MMD (:2354-2371)
+    default: *first = QMG_MATVEC_RIGHT_JACOBI; *second = QMG_MATVEC_RBJ_DAGGER; break;                       // apply_M_rbjacobi_MDM (:2282-2299)
+  }
+}
+template <typename T>
+inline void apply_normal_batch(BatchOp* op, qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask) {
+  QMGStencilType f1, f2;
+  normal_factors(op->type, &f1, &f2);
   qmg::BatchPoolT<T> pool(lhs.stride, lhs.nrhs);
   qmg::BatchT<T> t = pool.get();
-  if (!t.p || !st->apply_M_dagger_overwrite_batch_t<T>(t.p, rhs.p, lhs.nrhs, lhs.stride, mask)) return;
-  apply_M_overwrite_batch_t<T>(st, lhs, t, mask);
+  if (!t.p || !apply_factor_batch<T>(op->st, f1, t, rhs, mask)) return;
+  apply_factor_batch<T>(op->st, f2, lhs, t, mask);
+  if (op->normal_shift != 0.0) qmg::bcaxpy(qmg::cvec(lhs.nrhs, op->normal_shift), rhs, lhs, op->shift_length, mask);
 }
 template <typename T>
 inline void apply_stencil_typed_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, unsigned mask, void* extra_data) {
   BatchOp* op = (BatchOp*)extra_data;
   if (op->type == QMG_MATVEC_RIGHT_SCHUR) apply_M_rbjacobi_schur_batch<T>(op->st, lhs, rhs, mask);
-  else if (op->type == QMG_MATVEC_DAGGER) op->st->apply_M_dagger_overwrite_batch_t<T>(lhs.p, rhs.p, lhs.nrhs, lhs.stride, mask);
-  else if (op->type == QMG_MATVEC_M_MDAGGER) apply_M_M_dagger_batch<T>(op->st, lhs, rhs, mask);
-  else apply_M_overwrite_batch_t<T>(op->st, lhs, rhs, mask);
+  else if (BatchOp::is_normal(op->type)) apply_normal_batch<T>(op, lhs, rhs, mask);
+  else if (op->type == QMG_MATVEC_ORIGINAL) apply_M_overwrite_batch_t<T>(op->st, lhs, rhs, mask);
+  else apply_factor_batch<T>(op->st, op->type, lhs, rhs, mask);   // DAGGER, RIGHT_JACOBI, RBJ_DAGGER
 }
 // ---- the same applies with an EPILOGUE (Stencil2D::launch_set_epi), system by system, when ONE system is active: the BLAS-1 pass that
 // would follow the apply (residual, Schur combination, MR dots) happens on the finished site values inside the apply's launch.  A batch
@@ -250,14 +306,21 @@ inline bool apply_op_fused(BatchOp* op, qmg::BatchT<T> out, qmg::BatchT<T> x, co
     e.other = b ? (const void*)b->p : 0; e.other_scale = 1.0; e.acc_scale = b ? -1.0 : 1.0; e.dotv = mr_dots ? (const void*)x.p : 0;
     return st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, x.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e);
   }
-  if (op->type == QMG_MATVEC_M_MDAGGER) {   // M (M^dagger x): the MR dots of the CGNE smoother (against x) ride on the second apply
-    if (b || !mr_dots) return false;
+  if (op->type == QMG_MATVEC_RIGHT_JACOBI) {   // (1 + H') x: the same two forms on the right-block-Jacobi hops, the identity clover as a unit shift
+    if (!st->built_rbjacobi) return false;
+    e.other = b ? (const void*)b->p : 0; e.other_scale = 1.0; e.acc_scale = b ? -1.0 : 1.0; e.dotv = mr_dots ? (const void*)x.p : 0;
+    return st->launch_set_epi<T>(QMG_P_HOPPING | QMG_P_SHIFT | QMG_P_ZERO, out.p, x.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 1.0, 0.0, 0.0, out.stride, k, e);
+  }
+  if (op->type == QMG_MATVEC_M_MDAGGER || op->type == QMG_MATVEC_RBJ_M_MDAGGER) {   // A (A^dagger x): the MR dots of the CGNE smoother (against x) ride on the second apply
+    if (b || !mr_dots || op->normal_shift != 0.0) return false;
+    const bool rbj = op->type == QMG_MATVEC_RBJ_M_MDAGGER;
     qmg::BatchPoolT<T> pool(out.stride, out.nrhs);
     qmg::BatchT<T> t = pool.get();
-    if (!t.p || !st->apply_M_dagger_overwrite_batch_t<T>(t.p, x.p, out.nrhs, out.stride, mask)) return false;
+    if (!t.p || !apply_factor_batch<T>(st, rbj ? QMG_MATVEC_RBJ_DAGGER : QMG_MATVEC_DAGGER, t, x, mask)) return false;
     e.other = 0; e.other_scale = 0.0; e.acc_scale = 1.0; e.dotv = (const void*)x.p;
-    if (st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, t.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e)) return true;
-    apply_M_overwrite_batch_t<T>(st, out, t, mask);
+    if (rbj ? st->launch_set_epi<T>(QMG_P_HOPPING | QMG_P_SHIFT | QMG_P_ZERO, out.p, t.p, Stencil2D::QMG_ARR_RBJ_HOPPING, 1.0, 0.0, 0.0, out.stride, k, e)
+            : st->launch_set_epi<T>(QMG_P_ALL | QMG_P_ZERO, out.p, t.p, Stencil2D::QMG_ARR_ORIGINAL, st->shift, st->eo_shift, st->dof_shift, out.stride, k, e)) return true;
+    apply_factor_batch<T>(st, rbj ? QMG_MATVEC_RIGHT_JACOBI : QMG_MATVEC_ORIGINAL, out, t, mask);
     qmg::ok(qmg_batch_mr_dots_t(qmg::dtype_of<T>::value, x.p, out.p, (size_t)st->lat->get_size_cv_l(), out.nrhs, out.stride, mask, qmg::current_stream()), "qmg_batch_mr_dots");
     return true;
   }
@@ -299,12 +362,17 @@ inline void prepare_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<T> b
       qmg::bxmyz(b, b_prep, b_prep, half, mask);
     }
     qmg::bzero(batch_odd_half(b_prep, half), cv - half, mask);
-  } else qmg::bcopy(b_prep, b, cv, mask);
+  } else if (type == QMG_MATVEC_MDAGGER_M) apply_factor_batch<T>(st, QMG_MATVEC_DAGGER, b_prep, b, mask);            // M^dagger b (prepare_M_dagger_M, :1413-1422)
+  else if (type == QMG_MATVEC_RBJ_MDAGGER_M) apply_factor_batch<T>(st, QMG_MATVEC_RBJ_DAGGER, b_prep, b, mask);      // M_rbj^dagger b (prepare_M_rbjacobi_MDM, :2301-2318)
+  else qmg::bcopy(b_prep, b, cv, mask);
 }
 // x = reconstruct_M(y, b) (:2492-2527), x OVERWRITTEN
 template <typename T>
 inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<T> x, qmg::BatchT<T> y, qmg::BatchT<T> b, unsigned mask) {
   const size_t cv = (size_t)st->lat->get_size_cv_l(), half = cv / 2;
+  auto cinv = [&](qmg::BatchT<T> out, qmg::BatchT<T> in) {   // out = C^-1 in (apply_M_rbjacobi_cinv, :1848-1866)
+    st->launch_set_batch<T>(QMG_P_CLOVER | QMG_P_ZERO, out.p, in.p, Stencil2D::QMG_ARR_RBJ_CINV, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+  };
   if (type == QMG_MATVEC_RIGHT_SCHUR) {   // (:1932-1957) t_o = b_o - D'_oe y_e ; t_e = y_e ; x = C^-1 t
     qmg::BatchPoolT<T> pool(x.stride, x.nrhs);
     qmg::BatchT<T> t = pool.get();
@@ -316,7 +384,13 @@ inline void reconstruct_M_batch(Stencil2D* st, QMGStencilType type, qmg::BatchT<
       qmg::bxmyz(batch_odd_half(b, half), batch_odd_half(t, half), batch_odd_half(t, half), cv - half, mask);
     }
     qmg::bcopy(t, y, half, mask);
-    st->launch_set_batch<T>(QMG_P_CLOVER | QMG_P_ZERO, x.p, t.p, Stencil2D::QMG_ARR_RBJ_CINV, 0.0, 0.0, 0.0, x.nrhs, x.stride, mask);
+    cinv(x, t);
+  } else if (type == QMG_MATVEC_RIGHT_JACOBI || type == QMG_MATVEC_RBJ_MDAGGER_M) cinv(x, y);   // x = C^-1 y (reconstruct_M_rbjacobi :1870-1882, _MDM :2319-2335)
+  else if (type == QMG_MATVEC_M_MDAGGER) apply_factor_batch<T>(st, QMG_MATVEC_DAGGER, x, y, mask);   // x = M^dagger y (reconstruct_M_M_dagger, :1437-1446)
+  else if (type == QMG_MATVEC_RBJ_M_MDAGGER) {                                                       // x = C^-1 M_rbj^dagger y (reconstruct_M_rbjacobi_MMD, :2373-2392)
+    qmg::BatchPoolT<T> pool(x.stride, x.nrhs);
+    qmg::BatchT<T> t = pool.get();
+    if (t.p && apply_factor_batch<T>(st, QMG_MATVEC_RBJ_DAGGER, t, y, mask)) cinv(x, t);
   } else qmg::bcopy(x, y, cv, mask);
 }
 
@@ -709,6 +783,106 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
 }
 
 // ---------------------------------------------------------------------------------------------
+// CG with restarts for a batch: minv_vector_cg / minv_vector_cg_restart of krylov.hpp per system, in lock step (the coarsest solve on a
+// normal-equation operator, stateful_multigrid.h:930-960).  Every active system starts each restart cycle together; a system that converges,
+// breaks down (<p, A p> == 0) or reaches max_iter is frozen.  restart_freq <= 0: one cycle of max_iter iterations.
+// zero_guess: the caller has zeroed phi, the first cycle's r0 = b.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+inline std::vector<inversion_info> bcg_core(qmg::BatchT<T> phi, qmg::BatchT<T> phi0, int size, int max_iter, double eps, int restart_freq,
+                                            batch_matrix_op_t<T> matrix_vector, void* extra_info, unsigned mask, bool zero_guess,
+                                            inversion_verbose_struct* verb, const char* name, const std::vector<double>* eps_per_system = 0) {
+  const int nrhs = phi.nrhs;
+  std::vector<inversion_info> inv(nrhs);
+  std::vector<double> epsv(nrhs, eps);
+  if (eps_per_system) epsv = *eps_per_system;
+  qmg::BatchPoolT<T> pool(phi.stride, nrhs);
+  qmg::BatchT<T> r = pool.get(), p = pool.get(), Ap = pool.get();
+  const std::vector<double> bsq = qmg::bnorm2sq(phi0, size, mask);
+  std::vector<double> rsq(nrhs, 0.0), bnorm(nrhs, 0.0);
+  std::vector<int> its(nrhs, 0), ops(nrhs, 0);
+  std::vector<bool> conv(nrhs, false);
+  for (int k = 0; k < nrhs; k++) bnorm[k] = std::sqrt(bsq[k]);
+  const qmg::cvec one(nrhs, 1.0);
+  std::vector<qmg::BatchT<T> > pv(1);
+  unsigned live = (r.p && p.p && Ap.p) ? mask : 0u;   // systems that may still start a cycle
+  if (!live && mask) std::cout << "[QMG-ERROR]: " << name << ": out of device memory for the CG work vectors\n";
+  bool first = true;
+  while (live) {
+    // ---- one cycle (minv_vector_cg with at most `chunk` iterations per system)
+    std::vector<int> chunk(nrhs, 0), done_in_cycle(nrhs, 0);
+    unsigned act = 0;
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(live, k)) continue;
+      const int left = max_iter - its[k];
+      chunk[k] = (restart_freq > 0 && left > restart_freq) ? restart_freq : left;
+    }
+    if (first && zero_guess) { qmg::bcopy(r, phi0, size, live); rsq = bsq; }
+    else {
+      matrix_vector(Ap, phi, live, extra_info);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(live, k)) ops[k]++;
+      qmg::bxmyz(phi0, Ap, r, size, live);
+      const std::vector<double> t = qmg::bnorm2sq(r, size, live);
+      for (int k = 0; k < nrhs; k++) if (qmg::is_active(live, k)) rsq[k] = t[k];
+    }
+    first = false;
+    qmg::bcopy(p, r, size, live);
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(live, k)) continue;
+      conv[k] = (bnorm[k] == 0.0) || (std::sqrt(rsq[k]) < epsv[k] * bnorm[k]);
+      if (!conv[k] && chunk[k] > 0) act |= 1u << k;
+    }
+    while (act) {
+      matrix_vector(Ap, p, act, extra_info);
+      pv[0] = p;
+      const std::vector<qmg::cvec> d = qmg::bmultidot(pv, 1, Ap, size, act);   // <p, A p>
+      qmg::cvec alpha(nrhs, 0.0), malpha(nrhs, 0.0);
+      unsigned upd = 0;
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(act, k)) continue;
+        ops[k]++;
+        const double pAp = d[k][0].real();
+        if (pAp == 0.0) { act &= ~(1u << k); continue; }   // breakdown: this system's cycle ends (krylov.hpp `break`)
+        alpha[k] = rsq[k] / pAp; malpha[k] = -alpha[k];
+        upd |= 1u << k;
+      }
+      qmg::bcaxpy(alpha, p, phi, size, upd);
+      qmg::bcaxpy(malpha, Ap, r, size, upd);
+      const std::vector<double> rn = qmg::bnorm2sq(r, size, upd);
+      qmg::cvec beta(nrhs, 0.0);
+      unsigned go_on = 0;
+      for (int k = 0; k < nrhs; k++) {
+        if (!qmg::is_active(upd, k)) continue;
+        its[k]++; done_in_cycle[k]++;
+        if (verb && verb->verbosity == VERB_DETAIL) { std::cout << verb->verb_prefix << "CG"; if (nrhs > 1) std::cout << " rhs " << k; std::cout << " Iter " << its[k] << " RelTol " << std::sqrt(rn[k]) / bnorm[k] << "\n"; }
+        if (std::sqrt(rn[k]) < epsv[k] * bnorm[k]) { rsq[k] = rn[k]; conv[k] = true; act &= ~(1u << k); continue; }
+        beta[k] = rn[k] / rsq[k];
+        rsq[k] = rn[k];
+        if (done_in_cycle[k] >= chunk[k]) act &= ~(1u << k);
+        else go_on |= 1u << k;
+      }
+      qmg::bcaxpbyz(one, r, beta, p, p, size, go_on);   // p = r + beta p
+    }
+    // ---- which systems start another cycle (minv_vector_cg_restart: stop on success, on a cycle without an iteration, at max_iter)
+    unsigned next = 0;
+    for (int k = 0; k < nrhs; k++) {
+      if (!qmg::is_active(live, k)) continue;
+      if (restart_freq > 0 && !conv[k] && done_in_cycle[k] > 0 && its[k] < max_iter) next |= 1u << k;
+    }
+    live = next;
+  }
+  for (int k = 0; k < nrhs; k++) {
+    inv[k].success = conv[k]; inv[k].iter = its[k]; inv[k].resSq = rsq[k]; inv[k].ops_count = ops[k]; inv[k].name = name;
+    if (verb && verb->verbosity != VERB_NONE && qmg::is_active(mask, k)) {   // (one system: krylov.hpp's line, word for word)
+      std::cout << verb->verb_prefix << name;
+      if (nrhs > 1) std::cout << " rhs " << k;
+      std::cout << (conv[k] ? " Success " : " Fail ") << "Iter " << its[k] << " RelTol " << (bnorm[k] > 0 ? std::sqrt(rsq[k]) / bnorm[k] : 0.0) << "\n";
+    }
+  }
+  return inv;
+}
+
+// ---------------------------------------------------------------------------------------------
 // One K-cycle application for the active systems of a batch: StatefulMultigridMG::mg_preconditioner
 // (multigrid.hpp; stateful_multigrid.h:734-1060) step for step.  extra_data is a BatchKcycle.
 // ---------------------------------------------------------------------------------------------
@@ -716,18 +890,22 @@ struct BatchKcycle {
   StatefulMultigridMG* mg;
   int nrhs;
   BatchKcycle(StatefulMultigridMG* mg_, int nrhs_) : mg(mg_), nrhs(nrhs_) {}
-  // the configurations the batched cycle implements: ORIGINAL or RIGHT_SCHUR on every level, MR smoothers, GCR coarse solves
+  // the configurations the batched cycle implements: ORIGINAL, RIGHT_JACOBI or RIGHT_SCHUR levels with MR or CGNE smoothers and flexible-GCR
+  // intermediate solves; the coarsest solve by GCR on one of those operators or by CG on one of the four normal-equation forms -- every
+  // combination StatefulMultigridMG::mg_preconditioner takes -- provided the variant stencils they name have been built
   bool supported() {
     const int nl = mg->get_num_levels();
     if (nl < 2) return false;
     for (int i = 0; i < nl - 1; i++) {
       StatefulMultigridMG::LevelSolveMG* ls = mg->get_level_solve(i);
-      if (!ls || !BatchOp::supported(ls->fine_stencil_app)) return false;
-      // CGNE smoothers (MR on M M^dagger, then M^dagger: stateful_multigrid.h:847-857, 1032-1042) act on the ORIGINAL operator and need its dagger
-      // stencil; on the Schur operator the reference ignores the flag
-      if ((ls->pre_cgne || ls->post_cgne) && ls->fine_stencil_app == QMG_MATVEC_ORIGINAL && !(mg->get_stencil(i) && mg->get_stencil(i)->built_dagger)) return false;
+      if (!ls || !BatchOp::supported(ls->fine_stencil_app) || !BatchOp::variants_built(mg->get_stencil(i), ls->fine_stencil_app)) return false;
+      // CGNE smoothers (MR on A A^dagger, then A^dagger: stateful_multigrid.h:847-857, 1032-1042) act on the ORIGINAL and RIGHT_JACOBI operators and need
+      // the dagger stencil of that operator; on the Schur operator the reference ignores the flag
+      if ((ls->pre_cgne || ls->post_cgne) && ls->fine_stencil_app != QMG_MATVEC_RIGHT_SCHUR &&
+          !BatchOp::variants_built(mg->get_stencil(i), ls->fine_stencil_app == QMG_MATVEC_ORIGINAL ? QMG_MATVEC_DAGGER : QMG_MATVEC_RBJ_DAGGER)) return false;
     }
-    return BatchOp::supported(mg->get_coarsest_solve()->coarsest_stencil_app);
+    const QMGStencilType ct = mg->get_coarsest_solve()->coarsest_stencil_app;
+    return (BatchOp::supported(ct) || BatchOp::is_normal(ct)) && BatchOp::variants_built(mg->get_stencil(nl - 1), ct);
   }
   // complex<float> shadows of every level's matrices and null vectors, for the QMG_C32 K-cycle (the fp64 hierarchy stays
   // the master copy; call again after the hierarchy changes)
@@ -785,13 +963,14 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   int nact = 0;
   for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) nact++;
 
-  // One smoother application from x0 = 0: x ~ A^-1 b by `iters` steps of MR(0.85) -- or, `cgne` on the ORIGINAL operator, MR on M M^dagger y = b followed
-  // by x = M^dagger y (stateful_multigrid.h:847-857 / 1032-1042; on the Schur operator the reference ignores the flag).  Tolerances no MR step can
+  // One smoother application from x0 = 0: x ~ A^-1 b by `iters` steps of MR(0.85) -- or, `cgne` on the ORIGINAL / RIGHT_JACOBI operator, MR on A A^dagger y = b
+  // followed by x = A^dagger y (stateful_multigrid.h:847-857 / 1032-1042; on the Schur operator the reference ignores the flag).  Tolerances no MR step can
   // reach take the fixed-count form with its scalars on the device, which can also hand back its recursive residual b - A x (r_out; in the CGNE
   // form b - M M^dagger y is that same vector).  Returns whether r_out was filled.
   auto smooth = [&](qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T>* r_out, int iters, double tol, bool cgne, QMGDslashType type) -> bool {
-    const bool ne = cgne && fine_type == QMG_MATVEC_ORIGINAL;
-    BatchOp ne_op(fine_stencil, QMG_MATVEC_M_MDAGGER);
+    const bool ne = cgne && (fine_type == QMG_MATVEC_ORIGINAL || fine_type == QMG_MATVEC_RIGHT_JACOBI);
+    const bool rbj = fine_type == QMG_MATVEC_RIGHT_JACOBI;
+    BatchOp ne_op(fine_stencil, rbj ? QMG_MATVEC_RBJ_M_MDAGGER : QMG_MATVEC_M_MDAGGER);
     BatchOp* op = ne ? &ne_op : &fine_op;
     qmg::BatchT<T> y = ne ? fpool.get() : x;
     if (!y.p) { std::cout << "[QMG-ERROR]: out of device memory for the CGNE smoother's iterate\n"; return false; }
@@ -806,7 +985,7 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
       for (int k = 0; k < nrhs; k++) if (qmg::is_active(mask, k)) mg->add_tracker_count(type, (ne ? 2 : 1) * inv[k].ops_count, level);
     }
     if (ne) {
-      BatchOp dag(fine_stencil, QMG_MATVEC_DAGGER);
+      BatchOp dag(fine_stencil, rbj ? QMG_MATVEC_RBJ_DAGGER : QMG_MATVEC_DAGGER);
       apply_stencil_typed_batch<T>(x, y, mask, (void*)&dag);
       mg->add_tracker_count(type, nact, level);
     }
@@ -844,7 +1023,11 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   }
   qmg::bzero(e_coarse, coarse_size, mask);
   std::vector<inversion_info> cinv;
-  if (level == total_num_levels - 2) {
+  if (level == total_num_levels - 2 && BatchOp::is_normal(coarse_type)) {   // CG on a normal-equation operator, shifted by normal_shift (:930-960)
+    coarse_op.normal_shift = mg->get_coarsest_solve()->normal_shift; coarse_op.shift_length = coarse_size_solve;
+    cinv = bcg_core<T>(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch<T>, (void*)&coarse_op,
+                       mask, true, &verb2, coarse_restart == -1 ? "CG" : "CG-restart", &inner_tol);
+  } else if (level == total_num_levels - 2) {
     cinv = bgcr_core<T>(e_coarse, r_coarse_prep, (int)coarse_size_solve, coarse_max_iter, coarse_tol, coarse_restart, apply_stencil_typed_batch<T>, (void*)&coarse_op,
                         (batch_precond_op_t<T>)0, 0, mask, true, &verb2, coarse_restart == -1 ? "GCR" : "GCR-restart", &inner_tol);
   } else {

@@ -118,17 +118,20 @@ struct Stencil2D {
   struct F32Shadow {
     void* clover; void* hopping; void* rbj_hopping; void* rbj_cinv; bool on;
     void* dagger_clover; void* dagger_hopping;   // when the dagger stencil is built (CGNE smoothers of the fp32 K-cycle)
+    void* rbj_dagger_hopping;                    // when the right-block-Jacobi dagger stencil is built (CGNE smoothers / normal-equation solves on RIGHT_JACOBI levels)
     // optional (nc = 2): complex<half> copies of the matrices the smoother / residual applies of the fp32 K-cycle stream
     // (qmg_stencil_apply_h16: 112 B/site); cinv stays fp32 (it is applied once per cycle)
     void* clover16; void* hopping16; void* rbj_hopping16; bool half_on;
   } f32;
   // QMG_ARR_DAGGER: the dagger stencil (build_dagger_stencil) by name, without perform_swap_dagger -- the batch engine's CGNE smoothers; the caller passes
   // the conjugated shifts
-  enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2, QMG_ARR_DAGGER = 3 };
+  // QMG_ARR_RBJ_DAGGER: the hops of the right-block-Jacobi dagger stencil (build_rbj_dagger_stencil) by name; its clover is the identity (a unit shift)
+  enum QMGArraySet { QMG_ARR_ORIGINAL = 0, QMG_ARR_RBJ_HOPPING = 1, QMG_ARR_RBJ_CINV = 2, QMG_ARR_DAGGER = 3, QMG_ARR_RBJ_DAGGER = 4 };
+  static bool set_has_16bit_copy(QMGArraySet set) { return set == QMG_ARR_ORIGINAL || set == QMG_ARR_RBJ_HOPPING; }
   const void* clover_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? clover : set == QMG_ARR_RBJ_CINV ? rbjacobi_cinv : set == QMG_ARR_DAGGER ? dagger_clover : 0; }
-  const void* hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? hopping : set == QMG_ARR_RBJ_HOPPING ? rbjacobi_hopping_in_use() : set == QMG_ARR_DAGGER ? dagger_hopping : 0; }
+  const void* hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? hopping : set == QMG_ARR_RBJ_HOPPING ? rbjacobi_hopping_in_use() : set == QMG_ARR_DAGGER ? dagger_hopping : set == QMG_ARR_RBJ_DAGGER ? (swap_rbj_dagger ? hopping : rbj_dagger_hopping) : 0; }
   const void* f32_clover_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? f32.clover : set == QMG_ARR_RBJ_CINV ? f32.rbj_cinv : set == QMG_ARR_DAGGER ? f32.dagger_clover : 0; }
-  const void* f32_hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? f32.hopping : set == QMG_ARR_RBJ_HOPPING ? f32.rbj_hopping : set == QMG_ARR_DAGGER ? f32.dagger_hopping : 0; }
+  const void* f32_hopping_of(QMGArraySet set) const { return set == QMG_ARR_ORIGINAL ? f32.hopping : set == QMG_ARR_RBJ_HOPPING ? f32.rbj_hopping : set == QMG_ARR_DAGGER ? f32.dagger_hopping : set == QMG_ARR_RBJ_DAGGER ? f32.rbj_dagger_hopping : 0; }
 
   // Operators whose stencil is a fixed spin pattern times the gauge links (Wilson2D) can be applied straight from the links
   // (qmg_wilson_apply_direct, csrc/qmg_wilson.hip: 96 B/site instead of 384, bit-identical to the stored stencil through the
@@ -256,7 +259,7 @@ struct Stencil2D {
     eo_cvector = 0;
     f32_matrices = false; f32_bits = 32; clover32 = hopping32 = 0; rbj_hopping32 = rbj_cinv32 = 0;
     f32.clover = f32.hopping = f32.rbj_hopping = f32.rbj_cinv = 0; f32.on = false;
-    f32.dagger_clover = f32.dagger_hopping = 0;
+    f32.dagger_clover = f32.dagger_hopping = f32.rbj_dagger_hopping = 0;
     direct.gauge = 0; direct.gauge32 = 0; direct.w = 1.0; direct.on = false; direct.rbj_scale = 0.0;
     slab_halo_lo = slab_halo_hi = 0;
     slab_comm_stream = slab_ev_rhs = slab_ev_halo = 0;
@@ -306,6 +309,7 @@ struct Stencil2D {
     bool good = dup(&f32.clover, clover, lat->get_size_cm_l()) && dup(&f32.hopping, hopping, lat->get_size_hopping_l());
     if (good && built_rbjacobi) good = dup(&f32.rbj_hopping, rbjacobi_hopping, lat->get_size_hopping_l()) && dup(&f32.rbj_cinv, rbjacobi_cinv, lat->get_size_cm_l());
     if (good && built_dagger) good = dup(&f32.dagger_clover, dagger_clover, lat->get_size_cm_l()) && dup(&f32.dagger_hopping, dagger_hopping, lat->get_size_hopping_l());
+    if (good && built_rbj_dagger) good = dup(&f32.rbj_dagger_hopping, rbj_dagger_hopping, lat->get_size_hopping_l());
     if (good && half_matrices) {
       auto dup16 = [&](void** dst, const complex<double>* src, long n) -> bool {
         if (src == 0) return true;
@@ -326,7 +330,7 @@ struct Stencil2D {
     return true;
   }
   void disable_f32_shadow() {
-    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv, &f32.clover16, &f32.hopping16, &f32.rbj_hopping16, &f32.dagger_clover, &f32.dagger_hopping};
+    void** all[] = {&f32.clover, &f32.hopping, &f32.rbj_hopping, &f32.rbj_cinv, &f32.clover16, &f32.hopping16, &f32.rbj_hopping16, &f32.dagger_clover, &f32.dagger_hopping, &f32.rbj_dagger_hopping};
     for (auto p : all) if (*p) { qmg_free(*p); *p = 0; }
     f32.on = false; f32.half_on = false;
   }
@@ -566,7 +570,7 @@ struct Stencil2D {
         if (rc == QMG_SUCCESS) return;
         if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) { qmg::ok(rc, "qmg_wilson_hops_direct"); return; }
       }
-      if (f && f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER) {   // 16-bit stored matrices (nc = 2), fp32 vectors
+      if (f && f32.half_on && set_has_16bit_copy(set)) {   // 16-bit stored matrices (nc = 2), fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
         qmg::ok(qmg_stencil_apply_slab(QMG_C32 | QMG_SLAB_H16, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
@@ -596,7 +600,7 @@ struct Stencil2D {
     }
     if (sizeof(T) == sizeof(float)) {
       if (!f32.on) { std::cout << "[QMG-ERROR]: fp32 apply without an fp32 shadow (Stencil2D::enable_f32_shadow).\n"; return; }
-      if (f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER) {   // 16-bit stored matrices, fp32 vectors
+      if (f32.half_on && set_has_16bit_copy(set)) {   // 16-bit stored matrices, fp32 vectors
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;
         d.hopping = (set == QMG_ARR_ORIGINAL) ? f32.hopping16 : f32.rbj_hopping16;
         if (d.nc == 2) qmg::ok(qmg_stencil_apply_h16(&d, lhs, rhs, pieces, nrhs, stride, mask, qmg::current_stream()), "qmg_stencil_apply_h16");
@@ -652,7 +656,7 @@ struct Stencil2D {
     }
     int mat32 = 0;
     if (f) {
-      const bool half = f32.half_on && set != QMG_ARR_RBJ_CINV && set != QMG_ARR_DAGGER;
+      const bool half = f32.half_on && set_has_16bit_copy(set);
       if (!f32.on || (half && d.nc == 2)) return false;   // (kernel S, the 16-bit nc = 2 kernel, has no epilogue)
       if (half) {
         d.clover = (set == QMG_ARR_ORIGINAL) ? f32.clover16 : 0;

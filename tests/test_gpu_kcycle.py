@@ -335,3 +335,62 @@ def test_rbjacobi_hops_from_the_links_reproduce_the_stored_stencil_solve(golden_
         assert len(rows["1"]) == 2 and len(rows["0"]) == 2
         for a, b in zip(rows["1"], rows["0"]):
             assert abs(int(a[1]) - int(b[1])) <= 1 and float(a[3]) <= 1.05e-10
+
+
+def _kcycle_run(driver, args, env_extra, timeout=200):
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, QMG_QUIET="1", QMG_DUMP_DIR=d)
+        env.update(env_extra)
+        out = subprocess.run([os.path.join(DRIVERS, driver)] + args, cwd=DRIVERS, env=env, capture_output=True, text=True, timeout=timeout)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout, out.stdout[-3000:]
+        it = int(re.search(r"Multigrid converged in (\d+) iterations", out.stdout).group(1))
+        chk = float(re.search(r"Check tolerance ([-\d.e+]+)", out.stdout).group(1))
+        x = np.fromfile(os.path.join(d, "x.bin"), dtype=np.complex128)
+    return it, chk, x, out.stdout
+
+
+@pytest.mark.parametrize("hooks", [
+    {"QMG_SOLVE_TYPE": "jacobi"},
+    {"QMG_SOLVE_TYPE": "jacobi", "QMG_SMOOTHER": "cgne"},
+    {"QMG_SOLVE_TYPE": "jacobi", "QMG_COARSEST_TYPE": "rbj_mmd"},
+    {"QMG_SOLVE_TYPE": "jacobi", "QMG_COARSEST_TYPE": "rbj_mdm", "QMG_NORMAL_SHIFT": "0.01"},
+    {"QMG_COARSEST_TYPE": "rbj_mdm"},
+], ids=["jacobi", "jacobi-cgne", "jacobi-coarsest-MMdag", "jacobi-coarsest-MdagM-shifted", "schur-coarsest-MdagM"])
+def test_right_jacobi_levels_and_normal_coarsest_solves_in_both_engines(golden_dir, hooks):
+    """The branches of StatefulMultigridMG::mg_preconditioner no reference driver selects (stateful_multigrid.h:845-857 CGNE on a RIGHT_JACOBI level, :930-960 the
+    coarsest solve by CG on a normal-equation operator with normal_shift; stencil_2d.h:2418-2527 apply / prepare / reconstruct by type), reached through the n19
+    counterpart's environment hooks.  The lock-step batch engine (operators by name: right-block-Jacobi hops + unit shift, its dagger stencil, batched CG) against
+    the reference-shaped single-vector code of multigrid.hpp (perform_swap_*, minv_vector_cg): the same outer iteration count, the same reconstructed solution,
+    true residual against the ORIGINAL operator <= 1e-7 (tol 1e-8 on the preconditioned system).  Parity here is engine against engine: the reference holds no
+    output for these branches."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    args = ["128", "2", gauge_file, "64"]
+    b = _kcycle_run("n19_wilson_kcycle_precond", args, hooks)
+    s = _kcycle_run("n19_wilson_kcycle_precond", args, dict(hooks, QMG_KCYCLE_ENGINE="single"))
+    assert "solve type" in b[3]
+    assert b[1] <= 1e-7 and s[1] <= 1e-7, (b[:2], s[:2])
+    assert abs(b[0] - s[0]) <= 1, (b[:2], s[:2])
+    rel = np.linalg.norm(b[2] - s[2]) / np.linalg.norm(s[2])
+    assert rel < 1e-6, rel
+
+
+@pytest.mark.parametrize("ctype", ["mmd", "mdm"])
+def test_coarsest_cg_on_the_original_hierarchy_in_both_engines(golden_dir, ctype):
+    """n13's hierarchy with the coarsest solve by CG on M M^dagger / M^dagger M (CoarsestSolveMG::coarsest_stencil_app, stateful_multigrid.h:930-960; prepare_M /
+    reconstruct_M of those types, stencil_2d.h:1413-1446): batch engine (bcg_core, the dagger stencil by name) against the single-vector engine
+    (minv_vector_cg_restart, perform_swap_dagger) -- same outer iterations, same solution, true residual <= 1e-10; then three systems in lock step."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    args = ["128", "-0.07", "6.0", "2", "8", gauge_file, "64"]
+    b = _kcycle_run("n13_wilson_kcycle", args, {"QMG_COARSEST_TYPE": ctype})
+    s = _kcycle_run("n13_wilson_kcycle", args, {"QMG_COARSEST_TYPE": ctype, "QMG_KCYCLE_ENGINE": "single"})
+    assert b[1] <= 1.05e-10 and s[1] <= 1.05e-10, (b[:2], s[:2])
+    assert abs(b[0] - s[0]) <= 1, (b[:2], s[:2])
+    rel = np.linalg.norm(b[2] - s[2]) / np.linalg.norm(s[2])
+    assert rel < 1e-7, rel
+    out = subprocess.run([os.path.join(DRIVERS, "n13_wilson_kcycle_mrhs"), "128", "-0.07", "6.0", "2", "8", gauge_file, "64", "3", "verify"], cwd=DRIVERS,
+                         env=dict(os.environ, QMG_QUIET="1", QMG_COARSEST_TYPE=ctype), capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
+    rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+    assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-2000:]
