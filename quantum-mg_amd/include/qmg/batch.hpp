@@ -13,10 +13,9 @@
 // bit-identical to the single-vector ones, the MFMA apply and the blocked transfer differ in summation order only
 // (1e-13), so a batched solve reproduces the single solves to solver tolerance with the same iteration counts (+-1).
 //
-// Scope (this round): MR smoothers and GCR coarse solves with the ORIGINAL operator (n13, n22) or the right-block-Jacobi
-// Schur complement (n19) on every level (stateful_multigrid.h:734-1060 with fine_stencil_app / coarsest_stencil_app in
-// {QMG_MATVEC_ORIGINAL, QMG_MATVEC_RIGHT_SCHUR}, no CGNE/CGNR smoothers).  Other configurations are rejected loudly
-// (BatchKcycle::supported), not emulated.
+// Scope: every configuration of stateful_multigrid.h:734-1060 -- fine_stencil_app in {ORIGINAL, RIGHT_JACOBI, RIGHT_SCHUR} with MR or CGNE
+// smoothers and flexible-GCR intermediate solves; coarsest_stencil_app one of those (GCR) or one of the four normal-equation operators
+// (CG, normal_shift).  A hierarchy whose types name a variant stencil that is not built is rejected loudly (BatchKcycle::supported), not emulated.
 //
 // Storage precision: every type and function here is a template on the storage scalar T of the batch vectors (double |
 // float).  T = double is the engine described above.  T = float is the fp32 instantiation of the path (BASELINE
