@@ -367,6 +367,8 @@ int qmg_comm_finalize(void);
  *   qmg_comm_set_distributed_reductions   reductions of slab vectors are summed over the ranks inside the library.
  * Stencil arrays of a slab: qmg_wilson_fill_slab from the global gauge field (32 B/site, replicated). */
 #define QMG_SLAB_H16 0x100   /* or-ed into the storage argument: matrices stored as complex<half> (vectors QMG_C32) */
+#define QMG_SLAB_M32 0x200   /* nc != 2: matrices stored as complex<float> whatever the vectors' type (a preconditioner level's narrow Galerkin copy) */
+#define QMG_SLAB_M16 0x400   /* nc != 2, a multiple of 4: matrices stored as complex<half> whatever the vectors' type */
 int qmg_halo_exchange(int dtype, const void* vec, int Lx, int Ly_local, int nc, void* halo_lo, void* halo_hi, int nrhs, size_t vec_stride,
                       size_t halo_stride, void* stream);
 /* rows of one parity only (parities: bit 0 even sites' rows, bit 1 odd sites' rows): what a D_eo / D_oe piece reads; the vectors of the

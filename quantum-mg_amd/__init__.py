@@ -584,6 +584,8 @@ def comm_init_env(world, rank):
 
 
 SLAB_H16 = 0x100
+SLAB_M32 = 0x200   # nc != 2: complex<float> matrices whatever the vectors' type
+SLAB_M16 = 0x400   # nc != 2, a multiple of 4: complex<half> matrices
 
 
 def halo_exchange(dtype, vec, Lx, Ly_local, nc, halo_lo, halo_hi, nrhs=1, vec_stride=0, halo_stride=0, stream=None):

@@ -45,7 +45,7 @@ struct SlabHalo { const void* lo; const void* hi; long stride; int rows; };   //
 int site_kernel_apply(int storage, const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride,
                       const unsigned char* ridx, hipStream_t st, bool only_where_faster, const struct SlabHalo* slab);
 int generic_slab_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride, const unsigned char* ridx,
-                       hipStream_t st, const SlabHalo* slab, int f32);   // qmg_stencil.hip: kernel B with halos (any nc; f32: complex<float> matrices and vectors)
+                       hipStream_t st, const SlabHalo* slab, int mat32, int vec32);   // qmg_stencil.hip: kernel B with halos (any nc; f32: complex<float> matrices and vectors)
 constexpr int SITE_DECLINED = 1000;   // not an error: the caller's own kernel is the better one for this launch
 
 // qmg_comm.hip: reductions of y-slab vectors are summed over the ranks (qmg_comm_set_distributed_reductions)

@@ -354,9 +354,9 @@ int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, co
     if ((ev && od) || (pieces & (QMG_P_CLOVER | QMG_P_SHIFT))) return QMG_ERR_INVALID;
   }
   if (!valid_lattice(d->Lx, d->Ly)) return QMG_ERR_INVALID;
-  const bool h16 = storage & QMG_SLAB_H16;
-  const int dtype = storage & ~QMG_SLAB_H16;
-  if (!valid_dtype(dtype) || (h16 && dtype != QMG_C32)) return QMG_ERR_INVALID;
+  const bool h16 = storage & QMG_SLAB_H16, m32 = storage & QMG_SLAB_M32, m16 = storage & QMG_SLAB_M16;
+  const int dtype = storage & ~(QMG_SLAB_H16 | QMG_SLAB_M32 | QMG_SLAB_M16);
+  if (!valid_dtype(dtype) || (h16 && dtype != QMG_C32) || (m32 && m16) || ((m32 || m16) && d->nc == 2)) return QMG_ERR_INVALID;
   if (nrhs > 1 && (vec_stride < (size_t)d->Lx * d->Ly * d->nc || halo_stride < (size_t)d->Lx * d->nc)) return QMG_ERR_INVALID;
   unsigned char ridx[16];
   int n = 0;
@@ -365,9 +365,12 @@ int qmg_stencil_apply_slab(int storage, const qmg_stencil_desc* d, void* lhs, co
   if (n == 0) return QMG_SUCCESS;
   SlabHalo slab;
   slab.lo = halo_lo; slab.hi = halo_hi; slab.stride = (long)halo_stride; slab.rows = rows;
-  if (d->nc != 2) {   // any other nc: kernel B (all rows in one launch)
-    if (h16 || rows != 0) return QMG_ERR_UNSUPPORTED;
-    return generic_slab_apply(d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), &slab, dtype == QMG_C32 ? 1 : 0);
+  if (d->nc != 2) {   // any other nc: kernels B / B32 / C (all rows in one launch); matrices in the vectors' precision or narrower
+    if (rows != 0) return QMG_ERR_UNSUPPORTED;
+    const int vec32 = dtype == QMG_C32 ? 1 : 0;
+    const int mat = (h16 || m16) ? 2 : (m32 || vec32) ? 1 : 0;
+    if ((mat == 2 && (d->nc & 3)) || ((mat == 2 || m32) && d->nc <= 4)) return QMG_ERR_UNSUPPORTED;   // (narrow storage: the Galerkin levels, nc > 4)
+    return generic_slab_apply(d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), &slab, mat, vec32);
   }
   return site_kernel_apply(h16 ? 0 : (dtype == QMG_C32 ? 1 : 2), d, lhs, rhs, pieces, n, (long)vec_stride, ridx, as_stream(stream), false, &slab);
 }

@@ -875,9 +875,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_gen32(const StencilArgs a, co
           else if (piece == 1) nbsite = opp + (long)yp * a.hr + j;
           else if (piece == 2) { int jm = j + s - 1; if (jm < 0) jm = a.hr - 1; nbsite = opp + (long)y * a.hr + jm; }
           else nbsite = opp + (long)ym * a.hr + j;
+          // a slab's rows -1 / Ly: the opposite-parity row of the halo buffer (a row-uniform choice of base, stride and site: ONE load either way)
+          const bool halo = (piece == 1 && a.halo_hi && y + 1 == a.Ly) || (piece == 3 && a.halo_lo && y == 0);
+          const void* vbase = halo ? (piece == 1 ? a.halo_hi : a.halo_lo) : a.rhs;
+          const long vstride = halo ? a.halo_stride : a.vec_stride;
+          const long vsite = halo ? (long)(1 - p) * a.hr + j : nbsite;
 #pragma unroll
           for (int kk = 0; kk < KR; kk++)
-            if (kk < nk) xstage[f][kk] = ldv_raw<V32>(a.rhs, rhs_offset(a, k0 + kk) + nbsite * nc + cc);
+            if (kk < nk) xstage[f][kk] = ldv_raw<V32>(vbase, (long)system_index(a, k0 + kk) * vstride + vsite * nc + cc);
         }
       };
       // one piece: park set f (registers -> LDS), request piece `nextp` into the set just freed, compute
@@ -1723,7 +1728,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   a.vec32 = vec32;
   if (vec32 && !mat32) return QMG_ERR_UNSUPPORTED;   // fp32 vectors come with fp32 matrices (qmg_stencil_apply_t)
   // nc = 2 in one storage precision: the site kernel (kernel S, qmg_site.hip)
-  if (slab && mat32 != vec32) return QMG_ERR_UNSUPPORTED;   // slabs: kernel S (nc = 2) or kernel B (any nc), matrices and vectors in ONE precision
+  if (slab && nc == 2 && mat32 != vec32) return QMG_ERR_UNSUPPORTED;   // slabs at nc = 2: kernel S, matrices and vectors in ONE precision (or its own 16-bit form)
   if (epi && (norms_dev || nrhs != 1)) return QMG_ERR_UNSUPPORTED;   // the epilogue is served for ONE system per launch, by kernels B / B32
   if (nc == 2 && mat32 == vec32 && nrhs <= 16 && !norms_dev && !epi && (slab || (vec32 ? (g_stencil_site & 2) : (g_stencil_site & 5)))) {
     const int rc = site_kernel_apply(vec32 ? 1 : 2, d, lhs, rhs, pieces, nrhs, (long)vec_stride, ridx, as_stream(stream), !slab && !(g_stencil_site & 4), slab);
@@ -1938,7 +1943,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   }
 
   if (nc > BLOCK) return QMG_ERR_UNSUPPORTED;
-  if (a.mat32 && !(nc & 1) && g_gen32 && !slab) {   // (kernel B32 has no halo step: a slab's fp32 applies go through kernel B's widening loads)
+  if (a.mat32 && !(nc & 1) && g_gen32 && !(slab && nc <= 4)) {   // (a slab's fp32 applies at nc = 4 keep kernel B's widening loads)
     // kernel B32: fp32 tile end to end (even nc)
     const GenLayout L = make_gen_layout(nc, a.hr, g_gen32 == 2 ? 1 : 0);
     if (a.mat16 && (nc & 3)) return QMG_ERR_UNSUPPORTED;
@@ -1973,7 +1978,7 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
       }
     }
   }
-  if (a.mat16) return QMG_ERR_UNSUPPORTED;   // complex<half> matrices are served by kernel B32 only (nc a multiple of 4, no slabs)
+  if (a.mat16) return QMG_ERR_UNSUPPORTED;   // complex<half> matrices are served by kernels B32 / C only (nc a multiple of 4)
   GenLayout L = make_gen_layout(nc, a.hr, a.mat32);
   if (L.per_thread > GEN_MAX_PER_THREAD) return QMG_ERR_UNSUPPORTED;   // nc > 55: S = 1 still too large
   // right-hand sides per pass of kernel B: 4 (2-4 systems) or 8 accumulators; if the tile plus the vectors of the pass do
@@ -2023,9 +2028,9 @@ static int stencil_apply_impl(const qmg_stencil_desc* d, void* lhs, const void* 
   return QMG_SUCCESS;
 }
 
-// Generic-nc slab apply (csrc/qmg_site.hip holds the C entry qmg_stencil_apply_slab and serves nc = 2 itself): kernel B with the
-// right-hand side's rows -1 / Ly from the halo buffers, in fp64 or with complex<float> matrices and vectors.
+// Generic-nc slab apply (csrc/qmg_site.hip holds the C entry qmg_stencil_apply_slab and serves nc = 2 itself): kernels B / B32 / C with the
+// right-hand side's rows -1 / Ly from the halo buffers.  mat32: 0 fp64 matrices, 1 complex<float>, 2 complex<half>; vec32: complex<float> vectors.
 int qmg::generic_slab_apply(const qmg_stencil_desc* d, void* lhs, const void* rhs, unsigned pieces, int n, long vec_stride, const unsigned char* ridx,
-                            hipStream_t st, const SlabHalo* slab, int f32) {
-  return stencil_apply_impl(d, lhs, rhs, pieces, n, (size_t)vec_stride, ridx, (void*)st, f32, f32, slab);
+                            hipStream_t st, const SlabHalo* slab, int mat32, int vec32) {
+  return stencil_apply_impl(d, lhs, rhs, pieces, n, (size_t)vec_stride, ridx, (void*)st, mat32, vec32, slab);
 }

@@ -1073,7 +1073,11 @@ inline bool qmg_reserve_kcycle_scratch(StatefulMultigridMG* mg, size_t outer_siz
 // keeps the single-vector implementation of multigrid.hpp (A/B runs, and the reference-shaped code path for the parity tests).
 inline bool qmg_kcycle_via_batch(StatefulMultigridMG* mg, complex<double>* lhs, complex<double>* rhs, int size, inversion_verbose_struct* verb) {
   static const bool on = !(getenv("QMG_KCYCLE_ENGINE") && std::string(getenv("QMG_KCYCLE_ENGINE")) == "single");
-  if (!on || qmg::slab().on) return false;
+  // y-slabs take this engine too: launch_set_batch exchanges the batch's halo rows and every reduction is completed across the ranks (C3 shape on one
+  // slab / two thread-emulated slabs: 1.43 / 1.71 s against 1.71 / 2.24 s through the single-vector code).  QMG_KCYCLE_SLAB_ENGINE=single keeps slabs on
+  // the single-vector code, whose nc = 2 applies overlap their halo exchange with the interior rows -- the choice to re-measure on real xGMI links.
+  static const bool slab_on = !(getenv("QMG_KCYCLE_SLAB_ENGINE") && std::string(getenv("QMG_KCYCLE_SLAB_ENGINE")) == "single");
+  if (!on || (qmg::slab().on && !slab_on)) return false;
   BatchKcycle bk(mg, 1);
   if (!bk.supported()) return false;
   const size_t stride = (size_t)mg->get_lattice(mg->get_multigrid_level())->get_size_cv_l();

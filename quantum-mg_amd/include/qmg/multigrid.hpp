@@ -108,9 +108,9 @@ class MultigridMG {
   //       does not allow it keep complex<float>) -- opt-in (drivers: QMG_COARSE_BITS=16).
   static int& coarse_f32_storage() { static int f = -1; return f; }
   virtual bool coarse_f32_default() const { return false; }
-  // (y-slab mode keeps fp64 coarse matrices: the slab kernels stream the fp64 arrays; nc = 1, 2, 4 have no fp32-stored kernel)
+  // (nc = 1, 2, 4 have no fp32-stored kernel; y-slabs stream the narrow copies like a whole lattice: qmg_stencil_apply_slab with QMG_SLAB_M32 / _M16)
   bool coarse_f32_wanted(int nc) const {
-    if (qmg::slab().on || nc == 1 || nc == 2 || nc == 4) return false;
+    if (nc == 1 || nc == 2 || nc == 4) return false;
     const int f = coarse_f32_storage();
     return f < 0 ? coarse_f32_default() : f != 0;
   }

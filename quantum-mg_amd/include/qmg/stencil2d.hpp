@@ -173,6 +173,13 @@ struct Stencil2D {
         if (rc == QMG_SUCCESS) return true;
         if (rc != QMG_ERR_UNSUPPORTED && rc != QMG_ERR_INVALID) return qmg::ok(rc, "qmg_wilson_apply_direct");
       }
+      const void *ncl = 0, *nho = 0;
+      if (narrow_arrays_for(d.clover, d.hopping, &ncl, &nho)) {   // fp32 / 16-bit storage of a preconditioner level's matrices (enable_f32_matrices), fp64 vectors
+        qmg_stencil_desc dn = d;
+        dn.clover = ncl; dn.hopping = nho;
+        return qmg::ok(qmg_stencil_apply_slab(QMG_C64 | (f32_bits == 16 ? QMG_SLAB_M16 : QMG_SLAB_M32), &dn, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st),
+                       "qmg_stencil_apply_slab");
+      }
       return qmg::ok(qmg_stencil_apply_slab(QMG_C64, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, 1, 0, hs, 1u, rows, st), "qmg_stencil_apply_slab");
     };
     const bool overlap = par && qmg::slab().world > 1 && d.nc == 2 && d.Ly >= 4 && lhs != rhs && slab_overlap_ready();
@@ -292,7 +299,7 @@ struct Stencil2D {
     // inside half range
     if (half_matrices) {
       const int nc_ = lat->get_nc();
-      if (!(nc_ == 2 || (nc_ > 4 && (nc_ & 3) == 0 && !qmg::slab().on))) half_matrices = false;   // (slabs: the 16-bit slab kernel is kernel S, nc = 2)
+      if (!(nc_ == 2 || (nc_ > 4 && (nc_ & 3) == 0))) half_matrices = false;
       else if (nc_ != 2) {
         double big = std::max(clover ? norminf(clover, (size_t)lat->get_size_cm_l()) : 0.0, hopping ? norminf(hopping, (size_t)lat->get_size_hopping_l()) : 0.0);
         if (built_rbjacobi && rbjacobi_hopping) big = std::max(big, norminf(rbjacobi_hopping, (size_t)lat->get_size_hopping_l()));
@@ -377,7 +384,7 @@ struct Stencil2D {
   void narrow_rbjacobi_copies() {
     if (rbj_hopping32) { qmg_free(rbj_hopping32); rbj_hopping32 = 0; }
     if (rbj_cinv32) { qmg_free(rbj_cinv32); rbj_cinv32 = 0; }
-    if (!f32_matrices || !built_rbjacobi || swap_rbjacobi || swap_dagger || swap_rbj_dagger || qmg::slab().on) return;
+    if (!f32_matrices || !built_rbjacobi || swap_rbjacobi || swap_dagger || swap_rbj_dagger) return;
     int bits = f32_bits;
     if (bits == 16) {
       const double big = std::max(rbjacobi_hopping ? norminf(rbjacobi_hopping, (size_t)lat->get_size_hopping_l()) : 0.0, norminf(rbjacobi_cinv, (size_t)lat->get_size_cm_l()));
@@ -576,14 +583,17 @@ struct Stencil2D {
         qmg::ok(qmg_stencil_apply_slab(QMG_C32 | QMG_SLAB_H16, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
         return;
       }
+      int storage = dt;
       if (f) {
         d.clover = f32_clover_of(set);
         d.hopping = f32_hopping_of(set);
       } else {
         d.clover = clover_of(set);
         d.hopping = hopping_of(set);
+        const void *ncl = 0, *nho = 0;
+        if (narrow_arrays_for(d.clover, d.hopping, &ncl, &nho)) { d.clover = ncl; d.hopping = nho; storage |= (f32_bits == 16) ? QMG_SLAB_M16 : QMG_SLAB_M32; }   // (enable_f32_matrices)
       }
-      qmg::ok(qmg_stencil_apply_slab(dt, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
+      qmg::ok(qmg_stencil_apply_slab(storage, &d, lhs, rhs, slab_halo_lo, slab_halo_hi, pieces, nrhs, stride, hs, mask, 0, st), "qmg_stencil_apply_slab");
       return;
     }
     if (set == QMG_ARR_ORIGINAL && direct_usable(clover, hopping) && (sizeof(T) == sizeof(double) || direct.gauge32)) {

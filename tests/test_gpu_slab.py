@@ -192,9 +192,12 @@ def test_slab_entry_points_refuse_what_they_do_not_serve():
                                           C.c_size_t(0), C.c_size_t(0), C.c_uint(1), rows, None)
     assert call(qmg.C64, d4) == 0                                # any nc: kernel B with halos
     assert call(qmg.C64, d4, rows=1) == 3                        # ... but only all rows in one launch
-    assert call(qmg.C32 | qmg.SLAB_H16, d4) == 3                 # 16-bit matrices are an nc = 2 format
+    assert call(qmg.C32 | qmg.SLAB_H16, d4) == 3                 # 16-bit matrices: nc = 2, or the Galerkin levels (nc > 4, a multiple of 4)
+    assert call(qmg.C64 | qmg.SLAB_M32, d4) == 3 and call(qmg.C64 | qmg.SLAB_M16, d4) == 3
+    assert call(qmg.C64 | qmg.SLAB_M32 | qmg.SLAB_M16, d4) == 1  # one width
     d2 = qmg.make_desc(L, L, 2, cl, hp)
     assert call(qmg.C64 | qmg.SLAB_H16, d2) == 1                 # 16-bit matrices come with fp32 vectors
+    assert call(qmg.C64 | qmg.SLAB_M32, d2) == 1                 # narrow copies with wider vectors are not an nc = 2 format
     assert call(7, d2) == 1
     assert lib.qmg_stencil_apply_slab(qmg.C64, C.byref(d2), C.c_void_p(x.ptr), C.c_void_p(x.ptr), C.c_void_p(halo.ptr), C.c_void_p(halo.ptr), C.c_uint(0xFFF), 1,
                                       C.c_size_t(0), C.c_size_t(0), C.c_uint(1), 0, None) == 1          # in place
@@ -655,3 +658,75 @@ def test_staggered_and_laplace_solves_on_slabs_follow_the_one_slab_run():
                 assert it == it1, (name, R)
             else:
                 assert abs(it - it1) <= 12, (name, R)      # BiCGStab-6 steps come in sixes; its path follows the rounding
+
+
+@pytest.mark.parametrize("nc,nrhs,mask,bits,f32", [(8, 1, 0b1, 32, False), (24, 3, 0b101, 32, False), (12, 2, 0b11, 16, False), (24, 1, 0b1, 16, False),
+                                                   (8, 6, 0b111111, 32, False), (24, 8, 0xFF, 16, False), (8, 2, 0b11, 16, True), (24, 6, 0b111111, 16, True)])
+def test_narrow_stored_matrices_on_slabs(nc, nrhs, mask, bits, f32):
+    """A preconditioner level's narrow Galerkin copy on a slab (qmg_stencil_apply_slab with QMG_SLAB_M32 / QMG_SLAB_M16: complex<float> / complex<half> matrices,
+    complex<double> or complex<float> vectors; kernel B32 with its halo step for few systems, kernel C for batches): bit for bit the rows of the whole-lattice
+    apply on the same narrow arrays (qmg_stencil_apply_mat32 / qmg_stencil_apply_mat16_t)."""
+    Lx, Ly, R = 16, 16, 2
+    vol = Lx * Ly
+    n = vol * nc
+    vt = np.complex64 if f32 else np.complex128
+    dt = qmg.C32 if f32 else qmg.C64
+    clover, hopping = 0.3 * cs.gaussian_cvec(vol * nc * nc, 11), 0.3 * cs.gaussian_cvec(4 * vol * nc * nc, 12)
+    x, l0 = cs.gaussian_cvec(n * nrhs, 13).astype(vt), cs.gaussian_cvec(n * nrhs, 14).astype(vt)
+    shifts = (0.1 + 0.05j, 0.02, 0.03)
+    storage = "c32" if bits == 32 else "c16"
+    d = qmg.make_desc(Lx, Ly, nc, to_storage(clover, storage), to_storage(hopping, storage), *shifts)
+    pieces = qmg.P_ALL | qmg.P_ZERO
+    want = D(l0)
+    if bits == 16:
+        qmg.stencil_apply_mat16(dt, d, want, D(x), pieces, nrhs, n, mask)
+    else:
+        qmg.stencil_apply_mat32(d, want, D(x), pieces, nrhs, n, mask)
+    want = want.to_host()
+    Ll, row = Ly // R, (Lx // 2) * nc
+    nl = Lx * Ll * nc
+    xs = x.reshape(nrhs, 2, Ly, row)
+    flag = qmg.SLAB_M16 if bits == 16 else qmg.SLAB_M32
+    for r in range(R):
+        y0 = r * Ll
+        dl = qmg.make_desc(Lx, Ll, nc, to_storage(rows(clover, Ly, (Lx // 2) * nc * nc, y0, Ll), storage), to_storage(rows(hopping, Ly, (Lx // 2) * nc * nc, y0, Ll), storage), *shifts)
+        dx = D(np.concatenate([rows(x[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+        out = D(np.concatenate([rows(l0[k * n:(k + 1) * n], Ly, row, y0, Ll) for k in range(nrhs)]))
+        lo, hi = D(np.ascontiguousarray(xs[:, :, (y0 - 1) % Ly]).reshape(-1)), D(np.ascontiguousarray(xs[:, :, (y0 + Ll) % Ly]).reshape(-1))
+        qmg.stencil_apply_slab(dt | flag, dl, out, dx, lo, hi, pieces, nrhs, nl, 2 * row, mask, rows=0)
+        got = out.to_host()
+        for k in range(nrhs):
+            assert np.array_equal(got[k * nl:(k + 1) * nl], rows(want[k * n:(k + 1) * n], Ly, row, y0, Ll)), (nc, r, k)
+
+
+@pytest.mark.parametrize("R,extra", [(2, {}), (4, {"QMG_COARSE_BITS": "16"}), (2, {"QMG_KCYCLE_SLAB_ENGINE": "single"})])
+def test_kcycle_on_slabs_with_the_default_engine_and_storage(R, extra, monkeypatch):
+    """What a slab run does when nothing is switched off (this module's other tests pin fp64 coarse storage and the single-vector engine to compare digit by digit):
+    the lock-step batch engine as a batch of one system (qmg_kcycle_via_batch; QMG_KCYCLE_SLAB_ENGINE=single: the single-vector code) streaming the complex<float>
+    (QMG_COARSE_BITS=16: complex<half>) copies of the Galerkin matrices through the slab kernels.  One slab: the plain driver's outer iteration count; R thread-emulated
+    slabs: the same count (+-1), true residual < 1e-9, the same solution norm to 1e-9."""
+    import os
+    import re
+    import subprocess
+    for k in ("QMG_COARSE_F32", "QMG_KCYCLE_ENGINE", "QMG_APPLY_EPILOGUE"):
+        monkeypatch.delenv(k, raising=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drivers = os.path.join(root, "quantum-mg_amd", "drivers")
+    subprocess.check_call(["make", "-C", drivers, "-j4"], stdout=subprocess.DEVNULL)
+    gauge = os.path.join(root, "tests", "golden", "l64t64b60_heatbath.dat")
+    args = ["256", "-0.07", "6.0", "2", "8", gauge, "64"]
+    env = dict(os.environ, QMG_QUIET="1", QMG_NULL_BATCH="1")
+    env.update(extra)
+    plain = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle")] + args, cwd=drivers, env=env, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    many = subprocess.run([os.path.join(drivers, "n13_wilson_kcycle_slab")] + args, cwd=drivers, env=dict(env, QMG_COMM_EMULATE=str(R)), capture_output=True, text=True, timeout=900)
+    want_info = "complex<half>" if extra.get("QMG_COARSE_BITS") == "16" else "complex<float>"
+    for o in (plain, one, many):
+        assert o.returncode == 0 and want_info in o.stdout, o.stdout[-2500:] + o.stderr[-1500:]
+        assert "[QMG-ERROR]" not in o.stdout and "[QMG-WARNING]" not in o.stdout, o.stdout[-2500:]
+    it = lambda o: int(re.search(r"Multigrid converged in (\d+) iterations", o.stdout).group(1))
+    chk = lambda o: float(re.search(r"Check tolerance ([\d.e+-]+)", o.stdout).group(1))
+    xn = lambda o: float(re.search(r"\[QMG-SLAB\]: world \d+ ; \|b\| [\d.e+-]+ ; \|x\|\^2 ([\d.e+-]+)", o.stdout).group(1))
+    assert it(one) == it(plain) and chk(one) < 1e-9 and chk(plain) < 1e-9, (it(one), it(plain), chk(one), chk(plain))
+    assert abs(it(many) - it(one)) <= 1 and chk(many) < 1e-9, (it(many), it(one), chk(many))
+    assert abs(xn(many) - xn(one)) < 1e-9 * xn(one)
