@@ -528,7 +528,7 @@ def slab_kcycle(L, world, rank):
     t = re.search(r"\[QMG-TIMING\]: setup ([\d.e+-]+) s ; solve ([\d.e+-]+) s ; outer iterations/s ([\d.e+-]+)", p.stdout)
     if not (m and c and sl and t) or p.returncode != 0:
         return {"error": "rc %d" % p.returncode, "tail": (p.stdout + p.stderr)[-600:]}
-    return {"workload": "Wilson K-cycle (n13 parameters), %dx%d, 3 levels, coarse nc=8, fp64, ONE lattice cut into %d y-slab(s) on every level" % (L, L, world),
+    return {"workload": "Wilson K-cycle (n13 parameters), %dx%d, 3 levels, coarse nc=8, fp64 (Galerkin matrices stored as complex<float>, as on one domain), ONE lattice cut into %d y-slab(s) on every level" % (L, L, world),
             "scaling": "strong", "world": int(sl.group(1)), "converged": m.group(1) == "converged", "outer_iterations": int(m.group(2)),
             "true_residual": float(c.group(1)), "x_norm2": float(sl.group(3)), "setup_s": float(t.group(1)), "solve_s": float(t.group(2)),
             "outer_iterations_per_s": float(t.group(3))}
