@@ -71,8 +71,40 @@ __global__ __launch_bounds__(BLOCK) void k_bblas(void* __restrict__ z_, const vo
 // y_k += sum_j a[j][k] x_j,k for up to 8 vector sets per launch (coefficients travel as kernel arguments)
 constexpr int BMAXPY_J = 8;
 struct BatchMultiAxpy { const void* x[BMAXPY_J]; cplx a[BMAXPY_J][BATCH_MAX]; };
+// The NJ vector sets' loads are all requested (in storage form) before the first is widened and used: with a loop over nj and a branch on the
+// coefficient around each load, every load waited for the one before it.  A zero coefficient means "this system does not use vector
+// set j" (systems of a batch own different numbers of directions): the slot may hold stale pool memory, whose VALUE must not enter the sum
+// (0 * inf = nan) -- it is loaded like the others and replaced by zero.
+template <typename T, int W, int NJ, bool NT>
+__device__ __forceinline__ void bmulti_caxpy_run(typename CStore<T>::type* y, const BatchMultiAxpy& m, int k, long off, long np) {
+  typedef typename CStore<T>::type ct;
+  typedef typename RawP<T, W>::type raw;
+  cplx c[NJ];
+  bool use[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { c[j] = m.a[j][k]; use[j] = c[j].x != 0.0 || c[j].y != 0.0; }
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
+    raw ur[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const void* xb = reinterpret_cast<const ct*>(m.x[j]) + off;
+      ur[j] = NT ? ld_rawp_nt<T, W>(xb, i) : ld_rawp<T, W>(xb, i);
+    }
+    cplx acc[W];
+    ldc_pack<T, W>(y, i, acc);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      cplx u[W];
+      widen_rawp<T, W>(ur[j], u);
+#pragma unroll
+      for (int w = 0; w < W; w++) cmac(acc[w], c[j], use[j] ? u[w] : cmake(0.0, 0.0));
+    }
+    stc_pack<T, W>(y, i, acc);
+  }
+}
+// the short-vector form (coarse levels: a launch of a few microseconds, where the unrolled form's longer prologue costs more than its loads gain)
 template <typename T, int W>
-__global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, const BatchMultiAxpy m, int nj, const BatchIdx bi, long n, long stride) {
+__global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy_small(void* __restrict__ y_, const BatchMultiAxpy m, int nj, const BatchIdx bi, long n, long stride) {
   typedef typename CStore<T>::type ct;
   const int k = bi.id[blockIdx.y];
   const long off = (long)k * stride;
@@ -83,9 +115,7 @@ __global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, c
     ldc_pack<T, W>(y, i, acc);
     for (int j = 0; j < nj; j++) {
       const cplx c = m.a[j][k];
-      // a zero coefficient means "this system does not use vector set j" (systems of a batch own different numbers of
-      // directions): the slot may hold stale pool memory, which must not be read (0 * inf = nan)
-      if (c.x != 0.0 || c.y != 0.0) {
+      if (c.x != 0.0 || c.y != 0.0) {   // (a zero coefficient: the slot may hold stale pool memory, which must not be read)
         cplx u[W];
         ldb<T, W>(reinterpret_cast<const ct*>(m.x[j]) + off, i, u, bi.nt);
 #pragma unroll
@@ -94,6 +124,20 @@ __global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, c
     }
     stc_pack<T, W>(y, i, acc);
   }
+}
+template <typename T, int W>
+__global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, const BatchMultiAxpy m, int nj, const BatchIdx bi, long n, long stride) {
+  typedef typename CStore<T>::type ct;
+  const int k = bi.id[blockIdx.y];
+  const long off = (long)k * stride;
+  ct* y = reinterpret_cast<ct*>(y_) + off;
+  const long np = n / W;
+#define QMG_MAXPY_CASE(NJ) case NJ: if (bi.nt) bmulti_caxpy_run<T, W, NJ, true>(y, m, k, off, np); else bmulti_caxpy_run<T, W, NJ, false>(y, m, k, off, np); break;
+  switch (nj) {
+    QMG_MAXPY_CASE(1) QMG_MAXPY_CASE(2) QMG_MAXPY_CASE(3) QMG_MAXPY_CASE(4) QMG_MAXPY_CASE(5) QMG_MAXPY_CASE(6) QMG_MAXPY_CASE(7)
+    default: if (bi.nt) bmulti_caxpy_run<T, W, 8, true>(y, m, k, off, np); else bmulti_caxpy_run<T, W, 8, false>(y, m, k, off, np); break;
+  }
+#undef QMG_MAXPY_CASE
 }
 
 // ---------------- reductions (two-stage, deterministic; fp64: partition identical to qmg_blas.hip) ----------------
@@ -453,7 +497,11 @@ int qmg_batch_multi_caxpy_t(int dtype, const double* coeffs, const void* const* 
         m.a[j][k] = (j < jj && k < nrhs) ? make_double2(coeffs[((size_t)(j0 + j) * nrhs + k) * 2], coeffs[((size_t)(j0 + j) * nrhs + k) * 2 + 1])
                                          : make_double2(0.0, 0.0);
     }
-#define QMG_K(T, WW) k_bmulti_caxpy<T, WW><<<grid, BLOCK, 0, as_stream(stream)>>>(y, m, jj, bi, (long)n, (long)stride)
+    // vectors of 16 MB and more per system: all loads of a chunk in flight (same-box A/B, C5 shape: the outer flexible GCR's 4096^2 updates 4 % of the solve faster;
+    // the coarse levels' few-microsecond launches 1 % slower with it, hence the threshold)
+    const bool big = n * (dtype == QMG_C32 ? 8 : 16) >= ((size_t)16 << 20);
+#define QMG_K(T, WW) if (big) k_bmulti_caxpy<T, WW><<<grid, BLOCK, 0, as_stream(stream)>>>(y, m, jj, bi, (long)n, (long)stride); \
+                     else k_bmulti_caxpy_small<T, WW><<<grid, BLOCK, 0, as_stream(stream)>>>(y, m, jj, bi, (long)n, (long)stride)
     QMG_DISPATCH_TW(dtype, W, QMG_K);
 #undef QMG_K
     QMG_LAUNCH_CHECK();
