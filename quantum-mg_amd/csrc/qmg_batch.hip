@@ -576,11 +576,12 @@ int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y
   const unsigned g = bred_grid((long)(n / W));
   dim3 grid(g, (unsigned)bi.n);
   int j0 = 0;
-  while (j0 < nj) {   // same 4/2/1 chunking as qmg_multidot
+  while (j0 < nj) {   // same 8/4/2/1 chunking as qmg_multidot
     const int left = nj - j0;
-    const int kt = left >= 4 ? 4 : left >= 2 ? 2 : 1;
+    const int kt = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
 #define QMG_K(T, WW)                                                                                                  \
-    if (kt == 4) k_bmultidot<4, T, WW><<<grid, BLOCK, 0, st>>>(p, j0, y, (long)n, (long)stride, bi, ws->partials, nj);   \
+    if (kt == 8) k_bmultidot<8, T, WW><<<grid, BLOCK, 0, st>>>(p, j0, y, (long)n, (long)stride, bi, ws->partials, nj);   \
+    else if (kt == 4) k_bmultidot<4, T, WW><<<grid, BLOCK, 0, st>>>(p, j0, y, (long)n, (long)stride, bi, ws->partials, nj);   \
     else if (kt == 2) k_bmultidot<2, T, WW><<<grid, BLOCK, 0, st>>>(p, j0, y, (long)n, (long)stride, bi, ws->partials, nj); \
     else k_bmultidot<1, T, WW><<<grid, BLOCK, 0, st>>>(p, j0, y, (long)n, (long)stride, bi, ws->partials, nj)
     QMG_DISPATCH_TW(dtype, W, QMG_K);

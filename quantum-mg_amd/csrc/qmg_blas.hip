@@ -52,11 +52,25 @@ __global__ __launch_bounds__(BLOCK) void k_blas(cplx* __restrict__ z, const cplx
 // y += sum_i a_i x_i for up to 32 vectors in ONE pass (GCR orthogonalisation: 2k separate caxpy launches -> 2)
 constexpr int MAXPY_K = 32;
 struct MultiAxpy { const cplx* x[MAXPY_K]; cplx a[MAXPY_K]; };
+// NJ vectors' elements requested together, then accumulated in order j (the sum's order is that of the plain loop: bit-identical results).  A loop of one
+// load and one multiply-add per trip kept a single 16-byte load in flight per lane: 0.58 of the HBM rate on the outer GCR's 4096^2 updates.
+template <bool NT, int NJ>
+__device__ __forceinline__ void maxpy_chunk(cplx& acc, const MultiAxpy& m, int j0, long i) {
+  cplx u[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) u[j] = ldx<NT>(m.x[j0 + j], i);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) cmac(acc, m.a[j0 + j], u[j]);
+}
 template <bool NT>
 __global__ __launch_bounds__(BLOCK) void k_multi_caxpy(cplx* __restrict__ y, MultiAxpy m, int k, long n) {
   for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     cplx acc = y[i];
-    for (int j = 0; j < k; j++) cmac(acc, m.a[j], ldx<NT>(m.x[j], i));
+    int j = 0;
+    for (; j + 8 <= k; j += 8) maxpy_chunk<NT, 8>(acc, m, j, i);
+    if (k - j >= 4) { maxpy_chunk<NT, 4>(acc, m, j, i); j += 4; }
+    if (k - j >= 2) { maxpy_chunk<NT, 2>(acc, m, j, i); j += 2; }
+    if (k - j >= 1) maxpy_chunk<NT, 1>(acc, m, j, i);
     y[i] = acc;
   }
 }
@@ -447,12 +461,12 @@ int qmg_multidot(const void* const* xs, int k, const void* y, size_t n, double* 
   hipStream_t st = as_stream(stream);
   const unsigned g = red_grid((long)n);
   int k0 = 0;
-  while (k0 < k) {   // chunks of 4 / 2 / 1 vectors: y is re-read once per chunk
+  while (k0 < k) {   // chunks of 8 / 4 / 2 / 1 vectors: y is re-read once per chunk (each dot is its own accumulation: the chunking does not change a digit)
     const int rem = k - k0;
     const bool nt = blas_nt(n);
 #define QMG_MDOT(KT) { if (nt) k_multidot<KT, true><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); \
                        else k_multidot<KT, false><<<g, BLOCK, 0, st>>>(mp, k0, (const cplx*)y, (long)n, ws->partials, k); k0 += KT; }
-    if (rem >= 4) QMG_MDOT(4) else if (rem >= 2) QMG_MDOT(2) else QMG_MDOT(1)
+    if (rem >= 8) QMG_MDOT(8) else if (rem >= 4) QMG_MDOT(4) else if (rem >= 2) QMG_MDOT(2) else QMG_MDOT(1)
 #undef QMG_MDOT
     QMG_LAUNCH_CHECK();
   }
