@@ -403,10 +403,10 @@ class StatefulMultigridMG : public MultigridMG {
     if (total_num_levels > 1 && level_solve == 0) { std::cout << "[QMG-MG-SOLVE-ERROR]: Level solve for level " << level << " does not exist.\n"; return; }
     const long fine_size = mg->get_lattice(level)->get_size_cv_l();
     if (total_num_levels == 1) { copy_vector(lhs, rhs, fine_size); return; }   // :803-807
-    // ONE engine: configurations the lock-step batch engine implements (ORIGINAL or right-block-Jacobi Schur operators, MR
-    // smoothers, GCR coarse solves -- n13, n19, n22) run there as a batch of one system: same algorithm step for step, with the
-    // fixed-count smoothers' scalars on the device (batch.hpp).  Everything else (CGNE / CGNR smoothers, normal-equation
-    // coarsest solves, y-slab mode with its overlapped exchanges) continues below.
+    // ONE engine: every configuration runs in the lock-step batch engine as a batch of one system (batch.hpp: same algorithm step for
+    // step, the fixed-count smoothers' scalars on the device, apply epilogues).  What continues below is the reference-shaped
+    // single-vector code: QMG_KCYCLE_ENGINE=single (A/B runs, the digit-for-digit slab comparisons of the tests), QMG_KCYCLE_SLAB_ENGINE=single,
+    // and a hierarchy whose level types name a variant stencil that was not built (it warns exactly as the reference does).
     if (qmg_kcycle_via_batch(mg, lhs, rhs, size, verb)) return;
 
     Stencil2D* coarse_stencil = mg->get_stencil(level + 1);
