@@ -284,6 +284,14 @@ int qmg_batch_blas_t(int dtype, int op, const double* a, const double* b, const 
                      int nrhs, size_t stride, unsigned mask, void* stream);
 int qmg_batch_multi_caxpy_t(int dtype, const double* coeffs, const void* const* xs, int nj, void* y, size_t n,
                             int nrhs, size_t stride, unsigned mask, void* stream);
+/* The three vector updates of one flexible-GCR iteration (quantum-linalg's minv_vector_gcr_var_precond_restart as called at
+ * multigrid/stateful_multigrid.h:977-996 and tests/n13_wilson_kcycle/wilson_kcycle.cpp:459) in ONE pass, for the active systems k:
+ *   w_k += sum_j c[j][k] ws[j]_k   (Gram-Schmidt against the cycle's directions; nj >= 0, coeffs as for qmg_batch_multi_caxpy_t)
+ *   r_k += a[k] w_k                (a = -alpha; a[2k], a[2k+1] = re, im)
+ *   z_next_k = r_k                 (z_next != NULL: the next search direction of an un-preconditioned GCR)
+ * bit for bit qmg_batch_multi_caxpy_t, qmg_batch_blas_t(QMG_BOP_CAXPY), qmg_batch_blas_t(QMG_BOP_COPY) in that order.  w, r, z_next distinct. */
+int qmg_batch_gcr_update_t(int dtype, const double* coeffs, const void* const* ws, int nj, void* w, const double* a, void* r, void* z_next,
+                           size_t n, int nrhs, size_t stride, unsigned mask, void* stream);
 int qmg_batch_reduce_t(int dtype, int op, const void* x, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,
                        double* out_host, void* stream);
 int qmg_batch_multidot_t(int dtype, const void* const* xs, int nj, const void* y, size_t n, int nrhs, size_t stride, unsigned mask,

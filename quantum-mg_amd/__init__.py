@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_orthonormalize_n", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
-    "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
+    "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_gcr_update_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_convert_from_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_mat16_t", "qmg_stencil_apply_norm2",
     "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_staggered_fill_slab", "qmg_laplace_fill_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
@@ -542,6 +542,16 @@ def batch_multi_caxpy_t(dtype, coeffs, xs, y, n, nrhs, stride, mask):
     ptrs = (C.c_void_p * nj)(*[x.ptr for x in xs])
     check(lib().qmg_batch_multi_caxpy_t(dtype, cf.ctypes.data_as(C.POINTER(C.c_double)), ptrs, nj, _vp(y), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None),
           "qmg_batch_multi_caxpy_t")
+
+
+def batch_gcr_update_t(dtype, coeffs, ws, w, a, r, z_next, n, nrhs, stride, mask):
+    """w += sum_j c_j ws_j ; r += a w ; z_next = r (optional) in one pass (qmg_batch_gcr_update_t)"""
+    nj = len(ws)
+    cf = np.ascontiguousarray(np.asarray(coeffs, dtype=np.complex128).reshape(max(nj, 1), nrhs)).view(np.float64) if nj else None
+    ptrs = (C.c_void_p * max(nj, 1))(*[x.ptr for x in ws]) if nj else None
+    av = np.ascontiguousarray(np.asarray(a, dtype=np.complex128).reshape(nrhs)).view(np.float64)
+    check(lib().qmg_batch_gcr_update_t(dtype, cf.ctypes.data_as(C.POINTER(C.c_double)) if nj else None, ptrs, nj, _vp(w), av.ctypes.data_as(C.POINTER(C.c_double)), _vp(r),
+                                       _vp(z_next), C.c_size_t(n), nrhs, C.c_size_t(stride), C.c_uint(mask), None), "qmg_batch_gcr_update_t")
 
 
 def batch_reduce_t(dtype, op, x, y, n, nrhs, stride, mask):

@@ -140,6 +140,45 @@ __global__ __launch_bounds__(BLOCK) void k_bmulti_caxpy(void* __restrict__ y_, c
 #undef QMG_MAXPY_CASE
 }
 
+// The flexible GCR's three vector updates of one iteration in ONE pass (bgcr_core): w += sum_j c_j W_j (Gram-Schmidt), r += a w (a = -alpha; the w
+// just stored, in its storage precision), z_next = r (optional: the next search direction of an un-preconditioned GCR).  Operation for operation
+// k_bmulti_caxpy_small, k_bblas<CAXPY>, k_bblas<COPY> -- the same bits -- with one launch and one read of w and r instead of three launches.
+struct BatchCoefA { cplx a[BATCH_MAX]; };
+template <typename T, int W>
+__global__ __launch_bounds__(BLOCK) void k_bgcr_update(void* __restrict__ w_, const BatchMultiAxpy m, int nj, const BatchCoefA ar, void* __restrict__ r_,
+                                                       void* __restrict__ zn_, const BatchIdx bi, long n, long stride) {
+  typedef typename CStore<T>::type ct;
+  const int k = bi.id[blockIdx.y];
+  const long off = (long)k * stride;
+  ct* wv = reinterpret_cast<ct*>(w_) + off;
+  ct* rv = reinterpret_cast<ct*>(r_) + off;
+  ct* zn = zn_ ? reinterpret_cast<ct*>(zn_) + off : nullptr;
+  const cplx a = ar.a[k];
+  const long np = n / W;
+  for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < np; i += (long)gridDim.x * BLOCK) {
+    cplx acc[W], rr[W];
+    ldc_pack<T, W>(wv, i, acc);
+    ldc_pack<T, W>(rv, i, rr);
+    for (int j = 0; j < nj; j++) {
+      const cplx c = m.a[j][k];
+      if (c.x != 0.0 || c.y != 0.0) {   // (a zero coefficient: the slot may hold stale pool memory, which must not be read)
+        cplx u[W];
+        ldb<T, W>(reinterpret_cast<const ct*>(m.x[j]) + off, i, u, bi.nt);
+#pragma unroll
+        for (int q = 0; q < W; q++) cmac(acc[q], c, u[q]);
+      }
+    }
+    if (nj > 0) stc_pack<T, W>(wv, i, acc);
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+      if (sizeof(T) == 4) acc[q] = cmake((double)(float)acc[q].x, (double)(float)acc[q].y);   // what a separate pass would read back
+      cmac(rr[q], a, acc[q]);
+    }
+    stc_pack<T, W>(rv, i, rr);
+    if (zn) stc_pack<T, W>(zn, i, rr);
+  }
+}
+
 // ---------------- reductions (two-stage, deterministic; fp64: partition identical to qmg_blas.hip) ----------------
 template <int NV>
 __device__ __forceinline__ void bblock_reduce_store(double* v, double* partial_out) {
@@ -510,6 +549,39 @@ int qmg_batch_multi_caxpy_t(int dtype, const double* coeffs, const void* const* 
 }
 int qmg_batch_multi_caxpy(const double* coeffs, const void* const* xs, int nj, void* y, size_t n, int nrhs, size_t stride, unsigned mask, void* stream) {
   return qmg_batch_multi_caxpy_t(QMG_C64, coeffs, xs, nj, y, n, nrhs, stride, mask, stream);
+}
+
+// w_k += sum_j c[j][k] ws[j]_k ; r_k += a[k] w_k ; z_next_k = r_k (z_next != NULL) for the active systems: see k_bgcr_update
+int qmg_batch_gcr_update_t(int dtype, const double* coeffs, const void* const* ws, int nj, void* w, const double* a, void* r, void* z_next, size_t n, int nrhs,
+                           size_t stride, unsigned mask, void* stream) {
+  if (!valid_dtype(dtype) || nrhs < 1 || nrhs > BATCH_MAX || nj < 0 || (nj > 0 && (!coeffs || !ws)) || !a || ((!w || !r) && n)) return QMG_ERR_INVALID;
+  if (w == r || (z_next && (z_next == w || z_next == r))) return QMG_ERR_INVALID;
+  BatchIdx bi = expand_mask(mask, nrhs);
+  if (bi.n == 0 || n == 0) return QMG_SUCCESS;
+  // all but the last chunk of 8 vector sets: the plain multi-axpy.  Vectors of 16 MB and more per system (an outer solve on the fine lattice): every chunk
+  // through it -- its long-vector form keeps a chunk's loads in flight, which is worth more there than the saved launch (C5 shape: 2 % of the solve)
+  const bool big = n * (dtype == QMG_C32 ? 8 : 16) >= ((size_t)16 << 20);
+  const int lead = big ? nj : (nj > BMAXPY_J) ? ((nj - 1) / BMAXPY_J) * BMAXPY_J : 0;
+  if (lead > 0) { const int rc = qmg_batch_multi_caxpy_t(dtype, coeffs, ws, lead, w, n, nrhs, stride, mask, stream); if (rc) return rc; }
+  bi.nt = batch_nt(bi, n, dtype);
+  int W = pack_width(dtype, n, stride, nrhs, {w, r, z_next});
+  const int jj = nj - lead;
+  BatchMultiAxpy m;
+  for (int j = 0; j < BMAXPY_J; j++) {
+    m.x[j] = (j < jj) ? ws[lead + j] : nullptr;
+    if (j < jj && !ws[lead + j]) return QMG_ERR_INVALID;
+    if (j < jj && dtype == QMG_C32 && !aligned16(ws[lead + j])) W = 1;
+    for (int k = 0; k < BATCH_MAX; k++)
+      m.a[j][k] = (j < jj && k < nrhs) ? make_double2(coeffs[((size_t)(lead + j) * nrhs + k) * 2], coeffs[((size_t)(lead + j) * nrhs + k) * 2 + 1]) : make_double2(0.0, 0.0);
+  }
+  BatchCoefA ar;
+  for (int k = 0; k < BATCH_MAX; k++) ar.a[k] = (k < nrhs) ? make_double2(a[2 * k], a[2 * k + 1]) : make_double2(0.0, 0.0);
+  dim3 grid(grid_1d(n / W), (unsigned)bi.n);
+#define QMG_K(T, WW) k_bgcr_update<T, WW><<<grid, BLOCK, 0, as_stream(stream)>>>(w, m, jj, ar, r, z_next, bi, (long)n, (long)stride)
+  QMG_DISPATCH_TW(dtype, W, QMG_K);
+#undef QMG_K
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
 }
 
 // out_host[2*k + {0,1}] for every ACTIVE system k (inactive entries are left untouched); returns when they are on the host (wait_results)

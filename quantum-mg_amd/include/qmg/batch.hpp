@@ -143,6 +143,19 @@ inline void bmulti_caxpy(const std::vector<cvec>& c, const std::vector<BatchT<T>
   }
   ok(qmg_batch_multi_caxpy_t(dtype_of<T>::value, cf.data(), ptrs.data(), nj, y.p, n, y.nrhs, y.stride, mask, current_stream()), "qmg_batch_multi_caxpy");
 }
+// one flexible-GCR iteration's vector updates in one pass: w_k += sum_j c[k][j] Ws[j]_k ; r_k += a[k] w_k ; z_next_k = r_k (z_next.p != 0)
+template <typename T>
+inline void bgcr_update(const std::vector<cvec>& c, const std::vector<BatchT<T> >& Ws, int nj, BatchT<T> w, const cvec& a, BatchT<T> r, BatchT<T> z_next, size_t n, unsigned mask) {
+  std::vector<double> cf((size_t)2 * (nj > 0 ? nj : 1) * w.nrhs, 0.0), af((size_t)2 * w.nrhs, 0.0);
+  std::vector<const void*> ptrs(nj > 0 ? nj : 1, (const void*)0);
+  for (int j = 0; j < nj; j++) {
+    ptrs[j] = Ws[j].p;
+    for (int k = 0; k < w.nrhs; k++) { cf[((size_t)j * w.nrhs + k) * 2] = c[k][j].real(); cf[((size_t)j * w.nrhs + k) * 2 + 1] = c[k][j].imag(); }
+  }
+  for (int k = 0; k < w.nrhs; k++) { af[2 * k] = a[k].real(); af[2 * k + 1] = a[k].imag(); }
+  ok(qmg_batch_gcr_update_t(dtype_of<T>::value, nj > 0 ? cf.data() : 0, nj > 0 ? ptrs.data() : 0, nj, w.p, af.data(), r.p, z_next.p, n, w.nrhs, w.stride, mask, current_stream()),
+     "qmg_batch_gcr_update");
+}
 // z_k = x_k across storage precisions (round / widen), active systems only
 template <typename TD, typename TS>
 inline void bconvert(BatchT<TD> z, BatchT<TS> x, size_t n, unsigned mask) {
@@ -470,6 +483,8 @@ namespace qmg {
 inline bool mr_tolerance_unreachable(double eps) { return eps <= 1e-14; }
 // bgcr_core: the iteration's dots in one pass / one host round trip (see there).  QMG_GCR_FUSED=0 restores the three-pass form.
 inline bool gcr_fused_dots() { static const bool on = !(getenv("QMG_GCR_FUSED") && atoi(getenv("QMG_GCR_FUSED")) == 0); return on; }
+// ... and its vector updates in one pass (qmg_batch_gcr_update_t).  QMG_GCR_FUSED_UPDATE=0: the separate multi-axpy / axpy / copy passes.
+inline bool gcr_fused_update() { static const bool on = !(getenv("QMG_GCR_FUSED_UPDATE") && atoi(getenv("QMG_GCR_FUSED_UPDATE")) == 0); return on; }
 }  // namespace qmg
 template <typename T>
 inline int bmr_fixed_zero_guess(qmg::BatchT<T> x, qmg::BatchT<T> b, qmg::BatchT<T>* r_out, int size, int iters, double omega,
@@ -673,6 +688,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
     if (!conv[k] && max_iter > 0) act |= 1u << k;
   }
   int kb = 0;
+  bool z_ready = false;
   inversion_verbose_struct pverb(verb ? verb->precond_verbosity : VERB_NONE, verb ? verb->precond_verb_prefix : std::string(""));
   if (verb) { pverb.precond_verbosity = verb->precond_verbosity; pverb.precond_verb_prefix = verb->precond_verb_prefix; }
   std::vector<qmg::BatchT<T> > rw(2);
@@ -685,7 +701,8 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
       break;
     }
     if (precond) { qmg::bzero(z, size, act); precond(z, r, size, act, precond_info, &pverb); }
-    else qmg::bcopy(z, r, size, act);
+    else if (!z_ready) qmg::bcopy(z, r, size, act);   // (z_ready: the previous iteration's update pass wrote z = r already)
+    z_ready = false;
     matrix_vector(w, z, act, extra_info);
     // ONE reduction pass and one host round trip per iteration (qmg::gcr_fused_dots(); QMG_GCR_FUSED=0: the three-pass form): the Gram-Schmidt
     // coefficients c_i = <W_i, w>, <r, w> and <w, w> come from the same pass over the RAW w; for the orthogonalised w' = w - sum_i (c_i / N_i) W_i
@@ -694,6 +711,10 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
     // A system whose w' keeps less than 1e-6 of |w|^2 (w almost inside the span: the subtraction has lost its digits) takes the explicit dots.
     std::vector<qmg::cvec> d2(nrhs, qmg::cvec(2, 0.0));
     unsigned explicit_dots = act;
+    // With the dots of the fused form alpha is known BEFORE w is orthogonalised, so the Gram-Schmidt update of w, the residual update and (without a
+    // preconditioner) the copy z_next = r go through ONE pass (qmg_batch_gcr_update_t: the same bits as the three separate passes).
+    bool deferred = false;
+    std::vector<qmg::cvec> cdef;
     if (qmg::gcr_fused_dots()) {
       std::vector<qmg::BatchT<T> > basis(W.begin(), W.begin() + kb);
       basis.push_back(r); basis.push_back(w);
@@ -709,7 +730,8 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
         c[k].resize(kb);
         C[k][kb] = c[k];
       }
-      if (kb > 0) qmg::bmulti_caxpy(c, W, kb, w, size, act);
+      if (explicit_dots == 0 && qmg::gcr_fused_update()) { deferred = true; cdef = c; }
+      else if (kb > 0) qmg::bmulti_caxpy(c, W, kb, w, size, act);
     } else if (kb > 0) {
       std::vector<qmg::cvec> c = qmg::bmultidot(W, kb, w, size, act);
       for (int k = 0; k < nrhs; k++)
@@ -742,7 +764,15 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
       rsq[k] = rsq[k] - std::norm(wr) / ww;
       if (!(rsq[k] > 1e-8 * rsq_ref[k]) || std::sqrt(rsq[k]) < band * epsv[k] * bnorm[k]) renorm |= 1u << k;
     }
-    qmg::bcaxpy(malpha, w, r, size, upd);
+    if (deferred) {
+      qmg::BatchT<T> z_next;
+      if (!precond && kb + 1 < basis_max) {
+        if (kb + 1 == (int)Z.size()) { Z.push_back(pool.get()); W.push_back(pool.get()); Wnorm2.push_back(std::vector<double>(nrhs, 0.0)); }
+        z_next = Z[kb + 1];
+      }
+      qmg::bgcr_update(cdef, W, kb, w, malpha, r, z_next, size, upd);
+      z_ready = z_next.p != 0;
+    } else qmg::bcaxpy(malpha, w, r, size, upd);
     if (renorm) {
       const std::vector<double> t = qmg::bnorm2sq(r, size, renorm);
       for (int k = 0; k < nrhs; k++) if (qmg::is_active(renorm, k)) { rsq[k] = t[k]; rsq_ref[k] = t[k]; }
@@ -760,6 +790,7 @@ inline std::vector<inversion_info> bgcr_core(qmg::BatchT<T> phi, qmg::BatchT<T> 
       qmg::bxmyz(phi0, tmp, r, size, act);
       const std::vector<double> t = qmg::bnorm2sq(r, size, act);
       kb = 0;
+      z_ready = false;
       for (int k = 0; k < nrhs; k++) {
         if (!qmg::is_active(act, k)) continue;
         ops[k]++;

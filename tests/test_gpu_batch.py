@@ -351,3 +351,32 @@ def test_mr_step_with_device_scalars_is_the_host_scalar_step(nrhs, mask, dtype):
     qmg.batch_mr_dots(dt, gr3, zp, n, nrhs, stride, mask)
     qmg.batch_mr_update(dt, omega, gx3, gr3, gr3, zp, False, n, nrhs, stride, mask)
     assert np.array_equal(gx3.to_host(), x0) and np.array_equal(gr3.to_host(), r0)
+
+
+@pytest.mark.parametrize("nj,f32,with_z", [(0, False, True), (1, False, False), (3, False, True), (8, True, True), (11, False, True), (19, True, False)])
+def test_gcr_update_is_the_three_separate_passes_bit_for_bit(nj, f32, with_z):
+    """qmg_batch_gcr_update_t (w += sum_j c_j W_j ; r += a w ; z_next = r in one launch: the vector updates of one flexible-GCR iteration, the
+    caller of the K-cycle on both sides of the hot path) against qmg_batch_multi_caxpy_t, qmg_batch_blas_t(CAXPY), qmg_batch_blas_t(COPY) in that
+    order: identical bits in both storage precisions, frozen systems and the padding between systems untouched."""
+    nrhs, mask, n = 5, 0b10111, 4098
+    stride = n + 6
+    vt, dt = (np.complex64, qmg.C32) if f32 else (np.complex128, qmg.C64)
+    Ws = [cs.gaussian_cvec(stride * nrhs, 40 + j).astype(vt) for j in range(nj)]
+    w0, r0, z0 = (cs.gaussian_cvec(stride * nrhs, s).astype(vt) for s in (71, 72, 73))
+    coeffs = cs.gaussian_cvec(max(nj, 1) * nrhs, 8).reshape(max(nj, 1), nrhs)[:nj]
+    if nj >= 3:
+        coeffs[1, 2] = 0.0                      # "system 2 does not own direction 1"
+    a = cs.gaussian_cvec(nrhs, 9)
+    dW = [D(v) for v in Ws]
+    w1, r1, z1 = D(w0), D(r0), D(z0)
+    if nj:
+        qmg.batch_multi_caxpy_t(dt, coeffs, dW, w1, n, nrhs, stride, mask)
+    qmg.batch_blas_t(dt, qmg.BOP_CAXPY, r1, n, nrhs, stride, mask, a=a, x=w1)
+    if with_z:
+        qmg.batch_blas_t(dt, qmg.BOP_COPY, z1, n, nrhs, stride, mask, x=r1)
+    w2, r2, z2 = D(w0), D(r0), D(z0)
+    qmg.batch_gcr_update_t(dt, coeffs, dW, w2, a, r2, z2 if with_z else None, n, nrhs, stride, mask)
+    assert np.array_equal(w1.to_host().view(np.uint8), w2.to_host().view(np.uint8))
+    assert np.array_equal(r1.to_host().view(np.uint8), r2.to_host().view(np.uint8))
+    assert np.array_equal(z1.to_host().view(np.uint8), z2.to_host().view(np.uint8))
+    assert not np.array_equal(r2.to_host(), r0)
