@@ -29,7 +29,7 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
   const size_t n = (size_t)lat0->get_size_cv_l();
   {
     BatchKcycle probe(mg, 1);
-    if (solve_type != QMG_MATVEC_ORIGINAL && solve_type != QMG_MATVEC_RIGHT_SCHUR) { std::cout << "[QMG-ERROR]: this driver's outer solve is on the ORIGINAL or the RIGHT_SCHUR operator.\n"; return false; }
+    if (!BatchOp::supported(solve_type)) { std::cout << "[QMG-ERROR]: this driver's outer solve is on the ORIGINAL, RIGHT_JACOBI or RIGHT_SCHUR operator.\n"; return false; }
     if (!probe.supported()) { std::cout << "[QMG-ERROR]: the batched K-cycle does not implement this hierarchy's level / coarsest operator types (or a variant stencil they name is not built).\n"; return false; }
   }
   if (getenv("QMG_F32_KCYCLE")) f32_kcycle = true;
@@ -75,9 +75,11 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
         qmg::set_element(b.vec(1), 5, complex<double>(1.0, 0.0));
       }
       bsq = qmg::bnorm2sq(b, n, all);
-      // prepare (a copy for ORIGINAL; b_e - D'_eo b_o for the Schur system), solve, reconstruct -- as the drivers do for one system
-      const bool schur = solve_type == QMG_MATVEC_RIGHT_SCHUR;
-      qmg::Batch b_prep = schur ? pool.get() : b, y = schur ? pool.get() : x;
+      // prepare (a copy for ORIGINAL and RIGHT_JACOBI; b_e - D'_eo b_o for the Schur system), solve, reconstruct (RIGHT_JACOBI: x = C^-1 y) -- as the
+      // drivers do for one system
+      const bool schur = solve_type == QMG_MATVEC_RIGHT_SCHUR, precd = solve_type != QMG_MATVEC_ORIGINAL;
+      qmg::Batch b_prep = schur ? pool.get() : b, y = precd ? pool.get() : x;
+      if (b_prep.p == 0 || y.p == 0) { std::cout << "[QMG-ERROR]: out of device memory for a batch of " << nb << " systems\n"; return false; }
       BatchOp op0(mg->get_stencil(0), solve_type);
       if (schur) prepare_M_batch(mg->get_stencil(0), solve_type, b_prep, b, all);
       // the solve's scratch, outside its timed region: the batch's outer directions are full-stride vectors
@@ -98,7 +100,7 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
         if (repeats > 1) cout << "[QMG-MRHS]: repeat " << rep << " solve " << t_rep << " s (of which " << alloc_in_solve_s << " s in " << allocs_in_solve << " device allocator calls)\n";
         if (rep == repeats - 1) solve_s += t_rep;
       }
-      if (schur) reconstruct_M_batch(mg->get_stencil(0), solve_type, x, y, b, all);
+      if (precd) reconstruct_M_batch(mg->get_stencil(0), solve_type, x, y, b, all);
       apply_stencil_2D_M_batch(Ax, x, all, (void*)mg->get_stencil(0));   // true residual against the ORIGINAL operator
       rsq = qmg::bdiffnorm2sq(b, Ax, n, all);
       for (int k = 0; k < nb; k++) {
@@ -117,7 +119,7 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
           qmg_stream_sync(0);
           auto t1 = std::chrono::steady_clock::now();
           inversion_info i1;
-          if (!schur)
+          if (!precd)
             i1 = minv_vector_gcr_var_precond_restart(x1, b.vec(k), (int)n, max_iter, tol, restart_freq, apply_stencil_2D_M, (void*)mg->get_stencil(0),
                                                      StatefulMultigridMG::mg_preconditioner, (void*)mg, &vq);
           else {   // n19's sequence for one system
@@ -125,7 +127,7 @@ inline bool mrhs_solve_and_report(StatefulMultigridMG* mg, Lattice2D* lat0, int 
             complex<double>* y1 = mg->check_out(0);
             zero_vector(bp1, n); zero_vector(y1, n);
             mg->get_stencil(0)->prepare_M(bp1, b.vec(k), solve_type);
-            i1 = minv_vector_gcr_var_precond_restart(y1, bp1, (int)(n / 2), max_iter, tol, restart_freq, Stencil2D::get_apply_function(solve_type), (void*)mg->get_stencil(0),
+            i1 = minv_vector_gcr_var_precond_restart(y1, bp1, (int)(schur ? n / 2 : n), max_iter, tol, restart_freq, Stencil2D::get_apply_function(solve_type), (void*)mg->get_stencil(0),
                                                      StatefulMultigridMG::mg_preconditioner, (void*)mg, &vq);
             mg->get_stencil(0)->reconstruct_M(x1, y1, b.vec(k), solve_type);
             mg->check_in(y1, 0); mg->check_in(bp1, 0);

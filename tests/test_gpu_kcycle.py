@@ -394,3 +394,18 @@ def test_coarsest_cg_on_the_original_hierarchy_in_both_engines(golden_dir, ctype
     assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout
     rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
     assert len(rows) == 3 and all(float(r[3]) <= 1.05e-10 for r in rows), out.stdout[-2000:]
+
+
+def test_batched_right_jacobi_solves_follow_the_single_solves(golden_dir):
+    """Three systems in lock step with the outer solve, every level and the coarsest solve on the RIGHT_JACOBI operator and CGNE smoothers (n19 counterpart,
+    QMG_SOLVE_TYPE=jacobi, nrhs=3): each system converges, is reconstructed (x = C^-1 y) to a true residual <= 1e-7 against the ORIGINAL operator, and matches its
+    single-vector solve (QMG_MRHS_VERIFY: iteration counts within 1, solutions to 1e-6)."""
+    gauge_file = os.path.join(golden_dir, "l64t64b60_heatbath.dat")
+    out = subprocess.run([os.path.join(DRIVERS, "n19_wilson_kcycle_precond"), "128", "2", gauge_file, "64", "nrhs=3"], cwd=DRIVERS,
+                         env=dict(os.environ, QMG_QUIET="1", QMG_SOLVE_TYPE="jacobi", QMG_SMOOTHER="cgne", QMG_MRHS_VERIFY="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "[QMG-ERROR]" not in out.stdout and "[QMG-WARNING]" not in out.stdout, out.stdout[-3000:]
+    rows = re.findall(r"\[QMG-MRHS\]: rhs (\d+) converged in (\d+) iterations ; alleged tolerance ([-\d.e+]+) ; check tolerance ([-\d.e+]+)", out.stdout)
+    assert len(rows) == 3 and all(float(r[3]) <= 1e-7 for r in rows), out.stdout[-2000:]
+    ver = re.findall(r"\[QMG-MRHS-VERIFY\]: rhs (\d+) single-path iterations (\d+) \(batched (\d+)\) ; relative solution difference ([-\d.e+]+)", out.stdout)
+    assert len(ver) == 3 and all(abs(int(v[1]) - int(v[2])) <= 1 and float(v[3]) < 1e-6 for v in ver), ver

@@ -1,15 +1,3 @@
 # scratch: the command of the builder's last ad-hoc GPU call (gpurun -- 'bash tools/_gpucmd.sh'); not part of the product or of the collection scripts
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_batch.py -x -q 2>&1 | tail -2
-cd quantum-mg_amd/drivers
-G=../../tests/golden/l64t64b60_heatbath.dat
-for i in 1 2 3; do
-  for f in 1 0; do
-    echo "-- C3 fused_update=$f"; QMG_GCR_FUSED_UPDATE=$f QMG_QUIET=1 timeout -k 10 300 ./n13_wilson_kcycle 2048 -0.07 6.0 2 24 $G 64 2>&1 | grep -E "converged|^\[QMG-TIMING\]" | cut -c1-110
-  done
-done
-for i in 1 2; do
-  for f in 1 0; do
-    echo "-- C5 fused_update=$f"; QMG_GCR_FUSED_UPDATE=$f QMG_QUIET=1 timeout -k 10 300 ./n22_wilson_kcycle_adaptive 4096 -0.07 6.0 3 1 $G 64 schur nrhs=1 f32 2>&1 | grep -E "TIMING\]" | cut -c1-150
-  done
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_slab.py tests/test_gpu_kcycle.py -x -v -k "default_engine or batched_right_jacobi" > gpurun_out/t.log 2>&1; echo rc $?; tail -14 gpurun_out/t.log
