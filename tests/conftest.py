@@ -38,3 +38,9 @@ def pytest_collection_modifyitems(session, config, items):
         return rank.get(mod, len(_ORDER))
 
     items.sort(key=key)   # stable: the order inside a file is unchanged
+    # A GPU test that stops (a solve that stagnates on some configuration, a child that waits) must end as a FAILURE with a traceback, not
+    # as a silent run the box kills: the slowest GPU test takes 30 s, so 400 s per test is a hang.  (pytest-timeout, when the image has it.)
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+                item.add_marker(pytest.mark.timeout(400))
