@@ -336,6 +336,14 @@ int qmg_prolong_batch_t(int dtype, const void* nullvecs, int nvec, const void* c
                         int cLx, int cLy, int cnc, int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream);
 int qmg_restrict_batch_t(int dtype, const void* nullvecs, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
                          int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
+/* The same two operations (transfer/transfer.h:455-511) on complex<double> vectors with the null vectors STORED as complex<float> -- the narrow copy a
+ * preconditioner level keeps of its prolongator (half of the transfer's bytes; arithmetic fp64: the result is the fp64 operation with the rounded
+ * null vectors).  System by system through the single-vector kernels: meant for ONE active system (several share one read of the fp64 null vectors in
+ * qmg_*_batch_t instead).  Even fnc and block width, null vectors 16-byte aligned; QMG_ERR_UNSUPPORTED otherwise. */
+int qmg_prolong_batch_nv32(const void* nullvecs_c32, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc,
+                           int cLx, int cLy, int cnc, int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream);
+int qmg_restrict_batch_nv32(const void* nullvecs_c32, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc,
+                            int cLx, int cLy, int cnc, int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream);
 
 /* 16-bit storage of the fine operator (SURVEY 8f-4 "16-bit-storage smoother"; nc = 2 only): d->clover / d->hopping point to
  * complex<half> copies (qmg_convert_to_c16), vectors are complex<float>, arithmetic fp32: 112 B/site instead of 192.  The

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "qmg_prolong", "qmg_restrict", "qmg_block_orthonormalize", "qmg_block_orthonormalize_n", "qmg_block_bi_orthonormalize", "qmg_coarse_build", "qmg_set_tuning",
     "qmg_batch_blas", "qmg_batch_multi_caxpy", "qmg_batch_reduce", "qmg_batch_multidot", "qmg_prolong_batch", "qmg_restrict_batch",
     "qmg_comm_get_unique_id", "qmg_comm_init", "qmg_comm_init_env", "qmg_comm_rendezvous", "qmg_comm_all_ok", "qmg_comm_world", "qmg_allreduce_sum_f64", "qmg_comm_finalize",
-    "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_gcr_update_t", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
+    "qmg_convert", "qmg_stencil_apply_t", "qmg_batch_blas_t", "qmg_batch_multi_caxpy_t", "qmg_batch_gcr_update_t", "qmg_prolong_batch_nv32", "qmg_restrict_batch_nv32", "qmg_batch_reduce_t", "qmg_batch_multidot_t",
     "qmg_prolong_batch_t", "qmg_restrict_batch_t",
     "qmg_convert_to_c16", "qmg_convert_from_c16", "qmg_stencil_apply_h16", "qmg_stencil_apply_mat16_t", "qmg_stencil_apply_norm2",
     "qmg_wilson_apply_direct", "qmg_wilson_hops_direct", "qmg_halo_exchange", "qmg_halo_exchange_parity", "qmg_stencil_apply_slab", "qmg_wilson_fill_slab", "qmg_comm_set_distributed_reductions", "qmg_coarse_build_slab", "qmg_gaussian_slab", "qmg_rb_hopping_slab", "qmg_build_dagger_slab", "qmg_staggered_fill_slab", "qmg_laplace_fill_slab", "qmg_comm_emulate_begin", "qmg_comm_emulate_attach", "qmg_comm_emulate_end",
@@ -578,6 +578,17 @@ def prolong_batch_t(dtype, nullvecs, nvec, coarse, fine, fdims, cdims, nrhs, cst
 def restrict_batch_t(dtype, nullvecs, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
     check(lib().qmg_restrict_batch_t(dtype, _vp(nullvecs), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
           "qmg_restrict_batch_t")
+
+
+def prolong_batch_nv32(null32, nvec, coarse, fine, fdims, cdims, nrhs, cstride, fstride, mask):
+    """complex<double> vectors, complex<float> null vectors (qmg_prolong_batch_nv32)"""
+    check(lib().qmg_prolong_batch_nv32(_vp(null32), nvec, _vp(coarse), _vp(fine), *fdims, *cdims, nrhs, C.c_size_t(cstride), C.c_size_t(fstride), C.c_uint(mask), None),
+          "qmg_prolong_batch_nv32")
+
+
+def restrict_batch_nv32(null32, nvec, fine, coarse, fdims, cdims, nrhs, fstride, cstride, mask):
+    check(lib().qmg_restrict_batch_nv32(_vp(null32), nvec, _vp(fine), _vp(coarse), *fdims, *cdims, nrhs, C.c_size_t(fstride), C.c_size_t(cstride), C.c_uint(mask), None),
+          "qmg_restrict_batch_nv32")
 
 
 def convert_to_c16(dst, src, src_dtype, n):

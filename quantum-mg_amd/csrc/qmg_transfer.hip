@@ -32,7 +32,9 @@ __device__ __forceinline__ long coarse_site_index(const XferGeom& g, int cx, int
 // T = storage scalar of the null vectors and of both vectors; arithmetic in fp64 registers.
 // W = elements per lane: 1, or 2 for complex<float> with an even fnc -- then every access is one 16-byte load / store as in
 // fp64 (with 8-byte accesses the same number of instructions moves half the bytes: the fp32 prolong ran at 0.69 of peak).
-template <typename T, int W>
+// NS = storage scalar of the null vectors when it differs from the vectors' (complex<float> null vectors under complex<double> vectors: a
+// preconditioner level's narrow copy -- W = 2 there, so that a lane's null-vector load is still 16 bytes).
+template <typename T, int W, typename NS = T>
 __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ nullv, int nvec, const void* __restrict__ coarse,
                                                    void* __restrict__ fine, const XferGeom g) {
   const long row_packs = (long)g.fhr * g.fnc / W;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ null
       for (; d + 8 <= nvec; d += 8) {
         cplx v[8][W];
 #pragma unroll
-        for (int q = 0; q < 8; q++) ldc_pack_nt<T, W>(nullv, (long)(d + q) * (g.fsize / W) + kp, v[q]);
+        for (int q = 0; q < 8; q++) ldc_pack_nt<NS, W>(nullv, (long)(d + q) * (g.fsize / W) + kp, v[q]);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const cplx c = ldc<T>(coarse, cv + d + q);
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ null
       }
       for (; d < nvec; d++) {
         cplx v[W];
-        ldc_pack<T, W>(nullv, (long)d * (g.fsize / W) + kp, v);
+        ldc_pack<NS, W>(nullv, (long)d * (g.fsize / W) + kp, v);
         const cplx c = ldc<T>(coarse, cv + d);
 #pragma unroll
         for (int w = 0; w < W; w++) cmac(acc[w], v[w], c);
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_prolong(const void* __restrict__ null
 // null vectors at a time in registers; LDS sums the TPG partials.  One writer per (site, d): no atomics.
 constexpr int XFER_DC = 8;
 
-template <typename T, int W>
+template <typename T, int W, typename NS = T>
 __global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nullv, int nvec, const void* __restrict__ fine,
                                                     void* __restrict__ coarse, const XferGeom g, int NG, int TPG) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -105,20 +107,22 @@ __global__ __launch_bounds__(BLOCK) void k_restrict(const void* __restrict__ nul
           for (int el = l; el < G; el += TPG) {
             const long kp = base + el;
             // every load of the element first, in the storage form (qmg_common.h: a widening or a branch per load serialises them)
-            const typename RawP<T, W>::type fr = ld_rawp<T, W>(fine, kp);
-            typename RawP<T, W>::type vr[XFER_DC];
+            cplx f[W];
+            typename RawP<float, 2>::type fr32;   // (complex<float> vectors: kept raw until the null vectors are requested)
+            if constexpr (sizeof(T) == 4 && W == 2) fr32 = ld_rawp<T, W>(fine, kp);
+            else ldc_pack<T, W>(fine, kp, f);     // (complex<double>: nothing to widen; complex<float> one element per lane: the 8-byte form)
+            typename RawP<NS, W>::type vr[XFER_DC];
 #pragma unroll
             for (int q = 0; q < XFER_DC; q++) {
-              vr[q] = zero_rawp<T, W>();
-              if (q < dn) vr[q] = ld_rawp_nt<T, W>(nullv, (long)(d0 + q) * (g.fsize / W) + kp);   // read-once stream: non-temporal
+              vr[q] = zero_rawp<NS, W>();
+              if (q < dn) vr[q] = ld_rawp_nt<NS, W>(nullv, (long)(d0 + q) * (g.fsize / W) + kp);   // read-once stream: non-temporal
             }
-            cplx f[W];
-            widen_rawp<T, W>(fr, f);
+            if constexpr (sizeof(T) == 4 && W == 2) widen_rawp<T, W>(fr32, f);
 #pragma unroll
             for (int q = 0; q < XFER_DC; q++)
               if (q < dn) {
                 cplx v[W];
-                widen_rawp<T, W>(vr[q], v);
+                widen_rawp<NS, W>(vr[q], v);
 #pragma unroll
                 for (int w = 0; w < W; w++) cmac_conj(acc[q], v[w], f[w]);
               }
@@ -564,6 +568,33 @@ static int launch_prolong(const void* nullvecs, int nvec, const void* coarse, vo
   return QMG_SUCCESS;
 }
 
+// complex<double> vectors with complex<float> null vectors (a preconditioner level's narrow copy, TransferMG::enable_f32_shadow): two elements per lane,
+// so that a lane's null-vector load stays 16 bytes.  Even fnc, even block width, 16-byte aligned null vectors.
+static int launch_restrict_nv32(const void* null32, int nvec, const void* fine, void* coarse, const XferGeom& g, hipStream_t st) {
+  if ((g.bx & 1) || (g.fnc & 1) || (g.fsize & 1) || !aligned16(null32)) return QMG_ERR_UNSUPPORTED;
+  const int G = (g.bx / 2) * g.fnc / 2;
+  int NG = BLOCK / (G > 0 ? G : 1);
+  if (NG < 1) NG = 1;
+  const int cLx = 2 * g.chr;
+  if (NG > cLx) NG = cLx;
+  const int TPG = BLOCK / NG;
+  dim3 grid((unsigned)((cLx + NG - 1) / NG), g.cLy > 65535 ? 65535 : g.cLy);
+  k_restrict<double, 2, float><<<grid, BLOCK, sizeof(cplx) * BLOCK * XFER_DC, st>>>(null32, nvec, fine, coarse, g, NG, TPG);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+static int launch_prolong_nv32(const void* null32, int nvec, const void* coarse, void* fine, const XferGeom& g, hipStream_t st) {
+  if ((g.fnc & 1) || (g.fsize & 1) || !aligned16(null32)) return QMG_ERR_UNSUPPORTED;
+  const long row_packs = (long)g.fhr * g.fnc / 2;
+  unsigned gx = (unsigned)((row_packs + BLOCK - 1) / BLOCK);
+  if (gx > 1024) gx = 1024;
+  const int nrows = 2 * g.fLy;
+  dim3 grid(gx, nrows > 65535 ? 65535 : nrows);
+  k_prolong<double, 2, float><<<grid, BLOCK, 0, st>>>(null32, nvec, coarse, fine, g);
+  QMG_LAUNCH_CHECK();
+  return QMG_SUCCESS;
+}
+
 // qmg_transfer_mfma.hip: the batched transfers as contractions on the matrix cores (SITE_DECLINED: shapes not served there)
 int restrict_batch_mfma(int f32, const void* nullvecs, int nvec, const void* fine, void* coarse, int fhr, int fLy, int fnc, int chr, int cLy, int cnc, int bx, int by,
                         long fhalf_vol, long fsize, const int* ids8, int n, long cstride, long fstride, hipStream_t st);
@@ -679,6 +710,37 @@ int qmg_restrict(const void* nullvecs, int nvec, const void* fine, void* coarse,
   int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
   if (rc) return rc;
   return launch_restrict<double>(nullvecs, nvec, fine, coarse, g, as_stream(stream));
+}
+
+// complex<double> vectors, complex<float> null vectors: system by system through the single-vector kernels (the facade sends ONE active system here;
+// batches of several share one read of the fp64 null vectors in the tile kernels instead)
+int qmg_prolong_batch_nv32(const void* null32, int nvec, const void* coarse, void* fine, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                           int nrhs, size_t cstride, size_t fstride, unsigned mask, void* stream) {
+  if (!null32 || !coarse || !fine || nvec < 1 || nrhs < 1 || nrhs > BATCH_MAX) return QMG_ERR_INVALID;
+  XferGeom g;
+  int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
+  if (rc) return rc;
+  if (nvec != cnc) return QMG_ERR_INVALID;
+  const BatchIdx bi = expand_mask(mask, nrhs);
+  for (int s = 0; s < bi.n; s++) {
+    rc = launch_prolong_nv32(null32, nvec, (const cplx*)coarse + (size_t)bi.id[s] * cstride, (cplx*)fine + (size_t)bi.id[s] * fstride, g, as_stream(stream));
+    if (rc) return rc;
+  }
+  return QMG_SUCCESS;
+}
+int qmg_restrict_batch_nv32(const void* null32, int nvec, const void* fine, void* coarse, int fLx, int fLy, int fnc, int cLx, int cLy, int cnc,
+                            int nrhs, size_t fstride, size_t cstride, unsigned mask, void* stream) {
+  if (!null32 || !coarse || !fine || nvec < 1 || nrhs < 1 || nrhs > BATCH_MAX) return QMG_ERR_INVALID;
+  XferGeom g;
+  int rc = make_geom(&g, fLx, fLy, fnc, cLx, cLy, cnc);
+  if (rc) return rc;
+  if (nvec != cnc) return QMG_ERR_INVALID;
+  const BatchIdx bi = expand_mask(mask, nrhs);
+  for (int s = 0; s < bi.n; s++) {
+    rc = launch_restrict_nv32(null32, nvec, (const cplx*)fine + (size_t)bi.id[s] * fstride, (cplx*)coarse + (size_t)bi.id[s] * cstride, g, as_stream(stream));
+    if (rc) return rc;
+  }
+  return QMG_SUCCESS;
 }
 
 // transfer.h:455-511 for a lock-step batch, either storage precision

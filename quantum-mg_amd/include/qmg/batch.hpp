@@ -1041,7 +1041,7 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   // ---- 2. restrict, prepare, coarse solve (recursion = the "K"), reconstruct
   qmg::BatchT<T> r_coarse = cpool.get(), r_coarse_prep = cpool.get(), e_coarse = cpool.get(), e_rec = cpool.get();
   qmg::bzero(r_coarse, coarse_size, mask);
-  transfer->restrict_f2c_batch_t<T>(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
+  transfer->restrict_f2c_precond_t<T>(r1.p, r1.stride, r_coarse.p, r_coarse.stride, nrhs, mask);
   std::vector<double> inner_tol(nrhs, coarse_tol);
   if (coarse_type == QMG_MATVEC_ORIGINAL) qmg::bcopy(r_coarse_prep, r_coarse, coarse_size, mask);   // prepare_M is a copy; rnorm_prep == rnorm
   else {
@@ -1073,7 +1073,7 @@ inline void mg_preconditioner_batch(qmg::BatchT<T> lhs, qmg::BatchT<T> rhs, int 
   // ---- 3. prolong and correct: lhs = z1 + P e
   qmg::BatchT<T> z2 = r1;   // r1 is free again
   qmg::bzero(z2, fine_size, mask);
-  transfer->prolong_c2f_batch_t<T>(e_rec.p, e_rec.stride, z2.p, z2.stride, nrhs, mask);
+  transfer->prolong_c2f_precond_t<T>(e_rec.p, e_rec.stride, z2.p, z2.stride, nrhs, mask);
   if (coarse_type == QMG_MATVEC_RIGHT_SCHUR) qmg::bzero(batch_odd_half(z2, fine_size / 2), fine_size - fine_size / 2, mask);   // as multigrid.hpp
   qmg::bcxpyz(z1, z2, lhs, fine_size_solve, mask);
 

@@ -157,7 +157,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list.push_back(new CoarseOperator2D(new_lat, stencil_list[num_levels - 2], lattice_list[num_levels - 2], new_transfer, is_chiral,
                                                   build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra));
-      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list.back()->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32);
+      if (coarse_f32_wanted(new_lat->get_nc())) { stencil_list.back()->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32); new_transfer->enable_narrow_precond(); }
       is_stencil_managed.push_back(true);
     } else {
       stencil_list.push_back(0);
@@ -203,7 +203,7 @@ class MultigridMG {
     if (build_stencil) {
       stencil_list[level] = new CoarseOperator2D(new_lat, stencil_list[level - 1], lattice_list[level - 1], new_transfer, is_chiral,
                                                  build_stencil_from != QMG_MULTIGRID_PRECOND_ORIGINAL, build_extra);
-      if (coarse_f32_wanted(new_lat->get_nc())) stencil_list[level]->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32);
+      if (coarse_f32_wanted(new_lat->get_nc())) { stencil_list[level]->enable_f32_matrices(coarse_f32_storage() == 2 ? 16 : 32); new_transfer->enable_narrow_precond(); }
       is_stencil_managed[level] = true;
     } else {
       stencil_list[level] = 0;

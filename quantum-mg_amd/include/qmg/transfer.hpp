@@ -30,6 +30,7 @@ class TransferMG {
   bool is_init;
   void* null_store32;                // complex<float> shadow of null_store / restrict_store (enable_f32_shadow), or 0
   void* restrict_store32;
+  bool narrow_precond;               // the K-cycle's own transfers may stream the complex<float> copy under complex<double> vectors (enable_narrow_precond)
 
   bool geometry_ok() {
     fine_sites_per_coarse = fine_lat->get_nc();
@@ -67,7 +68,7 @@ class TransferMG {
   TransferMG(Lattice2D* in_fine_lat, Lattice2D* in_coarse_lat, complex<double>** in_null_vectors, bool do_block_ortho = true,
              bool save_decomp = false, QMGDoublingType in_doubling = QMG_DOUBLE_NONE)
       : fine_lat(in_fine_lat), coarse_lat(in_coarse_lat), const_num_null_vec(in_coarse_lat->get_nc()), null_store(0), restrict_store(0),
-        doubling(in_doubling), is_init(false), null_store32(0), restrict_store32(0), null_vectors(0), restrict_null_vectors(0), block_cholesky(0), block_L(0), block_U(0) {
+        doubling(in_doubling), is_init(false), null_store32(0), restrict_store32(0), narrow_precond(false), null_vectors(0), restrict_null_vectors(0), block_cholesky(0), block_L(0), block_U(0) {
     if (!geometry_ok()) return;
     null_store = copy_in(in_null_vectors);
     null_vectors = new complex<double>*[const_num_null_vec];
@@ -133,8 +134,17 @@ class TransferMG {
   void disable_f32_shadow() {
     if (null_store32) { qmg_free(null_store32); null_store32 = 0; }
     if (restrict_store32) { qmg_free(restrict_store32); restrict_store32 = 0; }
-  }
+  }   // (narrow_precond stays as it is: the narrow route also needs null_store32, and enable_f32_shadow re-creates the copy through here)
   bool has_f32_shadow() const { return null_store32 != 0; }
+  // Opt-in for a hierarchy that only PRECONDITIONS (StatefulMultigridMG under the same policy as Stencil2D::enable_f32_matrices): the K-cycle's own
+  // restrict / prolong of ONE system stream the complex<float> copy of the null vectors under complex<double> vectors -- half the bytes of an
+  // HBM-bound transfer (qmg_*_batch_nv32; arithmetic fp64).  The Galerkin build, prolong_c2f / restrict_f2c and the batch forms keep the fp64 vectors.
+  bool enable_narrow_precond() {
+    if (!null_store32 && !enable_f32_shadow()) return false;
+    narrow_precond = true;
+    return true;
+  }
+  void disable_narrow_precond() { narrow_precond = false; }
 
   bool is_initialized() { return is_init; }
 
@@ -181,6 +191,29 @@ class TransferMG {
     qmg::ok(qmg_restrict_batch_t(f ? QMG_C32 : QMG_C64, f ? r32 : r64, const_num_null_vec, fine, coarse, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1),
                                  fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), nrhs, fstride, cstride, mask,
                                  qmg::current_stream()), "qmg_restrict_batch_t");
+  }
+
+  // the K-cycle's own transfers (mg_preconditioner_batch): as the _batch_t forms, through the narrow copy where that is enabled and one system is active
+  template <typename T>
+  void prolong_c2f_precond_t(complex<T>* coarse, size_t cstride, complex<T>* fine, size_t fstride, int nrhs, unsigned mask) {
+    if (sizeof(T) == sizeof(double) && narrow_precond && null_store32 && (mask & (mask - 1)) == 0 && mask != 0) {
+      const int rc = qmg_prolong_batch_nv32(null_store32, const_num_null_vec, (const void*)coarse, (void*)fine, fine_lat->get_dim_mu(0), fine_lat->get_dim_mu(1), fine_lat->get_nc(),
+                                            coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), nrhs, cstride, fstride, mask, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED) { qmg::ok(rc, "qmg_prolong_batch_nv32"); return; }
+    }
+    prolong_c2f_batch_t<T>(coarse, cstride, fine, fstride, nrhs, mask);
+  }
+  template <typename T>
+  void restrict_f2c_precond_t(complex<T>* fine, size_t fstride, complex<T>* coarse, size_t cstride, int nrhs, unsigned mask) {
+    if (sizeof(T) == sizeof(double) && narrow_precond && null_store32 && (mask & (mask - 1)) == 0 && mask != 0) {
+      const int rc = qmg_restrict_batch_nv32(restrict_store32 ? restrict_store32 : null_store32, const_num_null_vec, (const void*)fine, (void*)coarse, fine_lat->get_dim_mu(0),
+                                             fine_lat->get_dim_mu(1), fine_lat->get_nc(), coarse_lat->get_dim_mu(0), coarse_lat->get_dim_mu(1), coarse_lat->get_nc(), nrhs, fstride,
+                                             cstride, mask, qmg::current_stream());
+      if (rc == QMG_SUCCESS) return;
+      if (rc != QMG_ERR_UNSUPPORTED) { qmg::ok(rc, "qmg_restrict_batch_nv32"); return; }
+    }
+    restrict_f2c_batch_t<T>(fine, fstride, coarse, cstride, nrhs, mask);
   }
 
   bool is_symmetric() { return restrict_store == 0; }

@@ -180,6 +180,34 @@ def test_transfer_f32_single_and_tiled(fd, cd, nrhs, mask):
             assert np.array_equal(got_f[fs], fine[fs]) and np.array_equal(got_c[csl], coarse[csl])
 
 
+@pytest.mark.parametrize("fd,cd,nrhs,mask", [((32, 32, 2), (8, 8, 8), 1, 1), ((64, 32, 2), (16, 8, 24), 3, 0b010), ((16, 16, 8), (4, 4, 8), 2, 0b11), ((16, 8, 24), (4, 2, 24), 1, 1),
+                                            ((24, 12, 2), (12, 6, 6), 2, 0b01)])
+def test_transfer_with_narrow_null_vectors_under_fp64_vectors(fd, cd, nrhs, mask):
+    """qmg_prolong_batch_nv32 / qmg_restrict_batch_nv32 (transfer/transfer.h:455-511 on complex<double> vectors with the null vectors stored as complex<float>:
+    what the K-cycle's own transfers stream in a hierarchy that only preconditions): the fp64 oracle on the ROUNDED null vectors to 1e-13 -- the arithmetic is
+    fp64, only the storage of the null vectors is narrow; frozen systems untouched."""
+    fsize, csize = fd[0] * fd[1] * fd[2], cd[0] * cd[1] * cd[2]
+    nvec = cd[2]
+    nv = r32(cs.gaussian_cvec(nvec * fsize, 1))                      # (values exactly representable in complex<float>)
+    fine, coarse = cs.gaussian_cvec(nrhs * fsize, 2), cs.gaussian_cvec(nrhs * csize, 3)
+    dn = D32(nv)
+    D = qmg.DeviceArray.from_host
+    df, dc = D(fine), D(coarse)
+    qmg.prolong_batch_nv32(dn, nvec, dc, df, fd, cd, nrhs, csize, fsize, mask)
+    got_f = df.to_host()
+    df2, dc2 = D(fine), D(coarse)
+    qmg.restrict_batch_nv32(dn, nvec, df2, dc2, fd, cd, nrhs, fsize, csize, mask)
+    got_c = dc2.to_host()
+    nv64 = nv.astype(np.complex128)
+    for k in range(nrhs):
+        fs, csl = slice(k * fsize, (k + 1) * fsize), slice(k * csize, (k + 1) * csize)
+        if (mask >> k) & 1:
+            assert cs.rel_l2(got_f[fs], ol.prolong(nv64, coarse[csl].copy(), fd, cd, fine=fine[fs].copy())) < 1e-13
+            assert cs.rel_l2(got_c[csl], ol.restrict(nv64, fine[fs].copy(), fd, cd, coarse=coarse[csl].copy())) < 1e-13
+        else:
+            assert np.array_equal(got_f[fs], fine[fs]) and np.array_equal(got_c[csl], coarse[csl])
+
+
 def test_convert_round_trip():
     x = cs.gaussian_cvec(10007, 9)
     d64, d32, back = qmg.DeviceArray.from_host(x), qmg.DeviceArray(10007, np.complex64), qmg.DeviceArray(10007)
