@@ -311,7 +311,7 @@ def kcycle_c5_schur_and_f32():
             out["fp32_over_fp64"] = out["fp32_kcycle"]["value"] / out["fp64"]["value"]
         if al:
             out["device_allocator_inside_solves_s"] = [float(a[0]) for a in al]
-        out["fp64"]["note"] = ("vectors and arithmetic fp64; the Galerkin matrices and right-block-Jacobi hops of the preconditioner levels are STORED as complex<float> "
+        out["fp64"]["note"] = ("vectors and arithmetic fp64; the Galerkin matrices, right-block-Jacobi hops and transfer null vectors of the preconditioner levels are STORED as complex<float> "
                                "(the facade's default for a hierarchy that only preconditions)")
         # the same fp64 solve with the reference's storage precision on every level, and with complex<half> storage (opt-in)
         for key, bits in (("fp64_strict_storage", "64"), ("fp64_16bit_storage", "16")):
@@ -636,7 +636,7 @@ def kcycle_c3(extra_env=None):
         ops = re.findall(r"Level (\d) .* Total (\d+)", p.stdout)
         al = re.search(r"device allocator inside the solve ([\d.e+-]+) s in (\d+) calls", p.stdout)
         f32c = "complex<float>" in p.stdout or "complex<half>" in p.stdout
-        return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, fp64, 1 GPU" + ("; Galerkin matrices of the preconditioner levels stored as complex<float> (the facade's default), arithmetic and vectors fp64" if f32c else ""),
+        return {"workload": "Wilson K-cycle (n13 parameters), 2048x2048, 3 levels, coarse nc=24, fp64, 1 GPU" + ("; Galerkin matrices of the preconditioner levels and the null vectors of the K-cycle's transfers stored as complex<float> (the facade's default), arithmetic and vectors fp64" if f32c else ""),
                 "metric": "outer VPGCR iterations per second",
                 "value": float(m.group(3)), "outer_iterations": int(it.group(2)), "converged": it.group(1) == "converged",
                 "true_residual": float(res.group(1)), "solve_s": float(m.group(2)), "setup_s": float(m.group(1)),

@@ -256,7 +256,7 @@ inline int N13::build(int argc, char** argv) {
   qmg_stream_sync(0);
   if (root && cgne) cout << "[QMG-INFO]: CGNE smoothers (MR on M M^dagger, then M^dagger) on every level\n";
   if (root && mg_object->any_coarse_f16()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<half> (QMG_COARSE_BITS=16; default 32, 64: fp64)\n";
-  else if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
+  else if (root && mg_object->any_coarse_f32()) cout << "[QMG-INFO]: Galerkin matrices of the preconditioner levels (and the null vectors of the K-cycle's own transfers) are stored as complex<float> (QMG_COARSE_F32=0: fp64)\n";
   setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup0).count();
   if (root) cout << setprecision(6) << "[QMG-SETUP-TIMING]: null vectors " << t_null << " s ; block orthonormalisation " << t_ortho << " s ; Galerkin build " << t_galerkin
        << " s ; total " << setup_s << " s\n" << setprecision(20);
