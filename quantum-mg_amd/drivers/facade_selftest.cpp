@@ -290,6 +290,28 @@ int main(int argc, char** argv) {
       check(worst_apply < 1e-13, o == 0 ? "batch applies by type == Stencil2D::apply_M by type (Wilson, 9 types x 3 systems)" : "batch applies by type == apply_M by type (Galerkin nc = 8, 9 types x 3 systems)", worst_apply);
       check(worst_prep < 1e-13, o == 0 ? "prepare_M_batch == prepare_M (Wilson)" : "prepare_M_batch == prepare_M (Galerkin nc = 8)", worst_prep);
       check(worst_rec < 1e-13, o == 0 ? "reconstruct_M_batch == reconstruct_M (Wilson)" : "reconstruct_M_batch == reconstruct_M (Galerkin nc = 8)", worst_rec);
+      // bcg_core (the coarsest solve of a normal-equation hierarchy) against minv_vector_cg / minv_vector_cg_restart, system by system: same iteration
+      // counts, the same solutions (element-wise kernels and reductions are the single-vector ones; an apply of several systems may sum in another order)
+      if (o == 1) {
+        for (int rf = -1; rf <= 16; rf += 17) {   // one cycle, and restarts every 16 iterations
+          BatchOp nop(st, QMG_MATVEC_MDAGGER_M);
+          qmg::bzero(out, n, all);
+          const std::vector<inversion_info> bi = bcg_core<double>(out, in, (int)n, 400, 1e-9, rf, apply_stencil_typed_batch<double>, (void*)&nop, all, true, (inversion_verbose_struct*)0,
+                                                                  rf == -1 ? "CG" : "CG-restart");
+          int worst_it = 0;
+          double worst_x = 0.0;
+          bool all_ok = true;
+          for (int k = 0; k < nb; k++) {
+            zero_vector(ref.vec(k), (long)n);
+            inversion_info si = (rf == -1) ? minv_vector_cg(ref.vec(k), in.vec(k), (int)n, 400, 1e-9, Stencil2D::get_apply_function(QMG_MATVEC_MDAGGER_M), (void*)st, &quiet)
+                                           : minv_vector_cg_restart(ref.vec(k), in.vec(k), (int)n, 400, 1e-9, rf, Stencil2D::get_apply_function(QMG_MATVEC_MDAGGER_M), (void*)st, &quiet);
+            all_ok = all_ok && si.success && bi[k].success;
+            worst_it = std::max(worst_it, std::abs(si.iter - bi[k].iter));
+            worst_x = std::max(worst_x, sqrt(diffnorm2sq(out.vec(k), ref.vec(k), (long)n) / norm2sq(ref.vec(k), (long)n)));
+          }
+          check(all_ok && worst_it <= 1 && worst_x < 1e-7, rf == -1 ? "bcg_core == minv_vector_cg per system (M^dag M, Galerkin nc = 8, 3 systems)" : "bcg_core == minv_vector_cg_restart(16) per system", worst_x);
+        }
+      }
       // a normal operator with CoarsestSolveMG::normal_shift (shift_function, stateful_multigrid.h:724-729)
       BatchOp sh(st, QMG_MATVEC_RBJ_MDAGGER_M);
       sh.normal_shift = complex<double>(0.37, 0.0); sh.shift_length = n;
